@@ -1,0 +1,87 @@
+"""Pin the CPU oracle (oracle/np_oracle.py) to the fixtures generated from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from oracle import initparams as ip
+
+G1 = dict(i=24, o=16, c=12, emb=30, h_enc=56, n_enc=2, h_dec=32, n_dec=2, B=3, seed=101, gain=2.0)
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def g1_params(dt=np.float64):
+    shapes = ip.molvae_shapes(G1["i"], G1["o"], G1["c"], G1["emb"], G1["h_enc"], G1["n_enc"], G1["h_dec"], G1["n_dec"])
+    return ip.init_params(shapes, G1["seed"], G1["gain"], dt)
+
+
+def test_g1_small_all_stages_and_grads(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_small.npz"))
+    p = g1_params()
+    r = O.molvae_loss_and_grads(p, g["idx"], g["eps"], max_len=G1["i"], num_lstm=G1["n_enc"], num_gru=G1["n_dec"])
+    assert abs(r["loss"] - float(g["loss"])) / abs(float(g["loss"])) < 1e-10
+    for k in ("mu", "logvar", "z", "recon"):
+        assert rel(r[k], g[k]) < 1e-9, k
+    for k in ("enc_emb", "enc_lstm_out", "enc_conv1", "enc_conv2", "enc_conv3", "enc_dense", "dec_latent", "dec_lstm_out"):
+        assert rel(r["stages"][k], g["stage." + k]) < 1e-9, k
+    names = [k[5:] for k in g.files if k.startswith("grad.")]
+    assert len(names) == len(r["grads"])
+    for k in names:
+        assert rel(r["grads"][k], g["grad." + k]) < 2e-6, k     # fixture grads stored as f32
+
+
+def test_g2_full_dims(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_full.npz"))
+    p = {k: v.astype(np.float64) for k, v in ip.init_params(ip.molvae_shapes(), 202, 1.5, np.float32).items()}
+    r = O.molvae_loss_and_grads(p, g["idx"], g["eps"], max_len=120)
+    assert abs(r["loss"] - float(g["loss"])) / abs(float(g["loss"])) < 1e-9
+    assert rel(r["mu"], g["mu"]) < 1e-8 and rel(r["logvar"], g["logvar"]) < 1e-8
+    assert rel(r["recon"][:, ::17, :], g["recon_rows"]) < 1e-8
+    assert abs(r["recon"].sum() - float(g["recon_sum"])) < 1e-6
+    for k, gr in r["grads"].items():
+        n = float(np.sqrt((gr ** 2).sum()))
+        assert abs(n - float(g["gnorm." + k])) <= 1e-7 * float(g["gnorm." + k]) + 1e-14, k
+        sl = gr.reshape(-1)[:: max(1, gr.size // 64)][:64]
+        assert rel(sl, g["gslice." + k]) < 1e-6, k
+
+
+def test_g4_clip_adam_trajectory(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_traj.npz"))
+    g1 = np.load(os.path.join(golden_dir, "g1_small.npz"))
+    p = g1_params()
+    state = {}
+    for step in range(5):
+        r = O.molvae_loss_and_grads(p, g1["idx"], g["eps"][step], max_len=G1["i"], num_lstm=G1["n_enc"], num_gru=G1["n_dec"])
+        assert abs(r["loss"] - g["losses"][step]) / g["losses"][step] < 1e-8, step
+        grads, total = O.clip_grad_norm(r["grads"], 3.0)
+        assert abs(total - g["gnorms"][step]) / g["gnorms"][step] < 1e-8
+        p = O.adam_step(p, grads, state, lr=8e-4)
+    for k, v in p.items():
+        assert abs(np.sqrt((v ** 2).sum()) - float(g["fnorm." + k])) < 1e-9 * (1 + float(g["fnorm." + k])), k
+        assert rel(v.reshape(-1)[:: max(1, v.size // 64)][:64], g["fslice." + k]) < 1e-8, k
+
+
+def test_g3_moses_gru_path(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_moses.npz"))
+    V = int(g["V"])
+    p = ip.init_params(ip.moses_shapes(V), 303, 1.5, np.float64)
+    seqs = [g[f"seq{b}"] for b in range(6)]
+    r = O.moses_forward(p, seqs, g["eps"], int(g["pad"]))
+    assert abs(r["kl"] - float(g["kl"])) < 1e-10 * abs(float(g["kl"]))
+    assert abs(r["recon"] - float(g["recon"])) < 1e-10 * abs(float(g["recon"]))
+    assert rel(r["z"], g["z"]) < 1e-9 and rel(r["logvar"], g["logvar"]) < 1e-9
+    assert rel(r["y"], g["y"]) < 1e-6                          # y stored as f32
+    assert (r["x_pad"] == g["x"]).all()
+    grads = r["grads_for"](float(g["kl_w"]))
+    names = list(g["grad_names"])
+    assert sorted(grads.keys()) == sorted(names)
+    for k in names:
+        gr = grads[k]
+        n = float(np.sqrt((gr ** 2).sum()))
+        assert abs(n - float(g["gnorm." + k])) <= 1e-8 * float(g["gnorm." + k]) + 1e-14, k
+        assert rel(gr.reshape(-1)[:: max(1, gr.size // 64)][:64], g["gslice." + k]) < 1e-7, k
