@@ -1,0 +1,234 @@
+/* mvae.h -- C ABI of libmvae_hip.so: the MI355X (gfx950) kernels behind the SMILES-VAE training hot path.
+ *
+ * The reference (aclyde11/molecular-VAE) has no FFI or plugin layer: its hot path is the Python nn.Module
+ * surface of models.py / mosesvae.py and the loop body of train.py:94-104, and all arithmetic is delegated
+ * to torch.nn primitives.  This header is therefore the boundary the build defines *beneath* that surface
+ * (SURVEY.md section 8b): one entry point per fused op x {fwd,bwd}; each comment names the reference call
+ * site (file:line under /root/reference) whose torch primitive it replaces.
+ *
+ * Conventions
+ *  - raw DEVICE pointers, caller-owned (the library never allocates or frees caller memory);
+ *  - an explicit stream (hipStream_t passed as void*); every call is asynchronous on it and graph-capturable
+ *    (no allocation, no synchronisation inside);
+ *  - returns 0 on success, a negative MVAE_ERR_* for bad arguments, a positive hipError_t otherwise;
+ *    never throws, never aborts;
+ *  - no hidden RNG: noise (eps) is an input pointer;
+ *  - matrices are row-major with explicit leading dimensions (in elements).  GEMM operands are read in
+ *    16-byte chunks along K: K-extents that are not a multiple of the chunk (4 f32 / 8 bf16) require the
+ *    rows to be zero-padded up to the next chunk boundary (the library's own producers do this);
+ *  - dtype codes select the storage type of activations/weights inside the recurrent and GEMM kernels;
+ *    accumulation, cell state, reductions, loss and optimiser state are always fp32.
+ */
+#ifndef MVAE_H_
+#define MVAE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVAE_ABI_VERSION 1
+
+#define MVAE_OK 0
+#define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
+#define MVAE_ERR_WORKSPACE (-2)   /* workspace too small */
+#define MVAE_ERR_UNSUPPORTED (-3) /* combination not implemented */
+
+#define MVAE_F32 0
+#define MVAE_BF16 1
+
+#define MVAE_ACT_NONE 0
+#define MVAE_ACT_SELU 1           /* models.py:58-68 */
+
+#define MVAE_CELL_LSTM 0          /* torch.nn.LSTM, gate rows [i;f;g;o]  (models.py:117,156) */
+#define MVAE_CELL_GRU 1           /* torch.nn.GRU,  gate rows [r;z;n]    (mosesvae.py:54-61,73-79) */
+
+#define MVAE_MAX_LAYERS 8
+
+int mvae_abi_version(void);
+const char* mvae_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Dense contraction  C[M,N] = act( A[M,K] . B[N,K]^T + bias[N] )          (MFMA, fp32 accumulate)
+ * Replaces nn.Linear at models.py:122,87-88,153,157 and mosesvae.py:66-67,81-82, and is the GEMM under the
+ * conv / weight-gradient ops below.  dtype_ab: storage of A and B; dtype_c: storage of C.
+ * accumulate != 0: C += result (fp32 C only).  ws: scratch for split-K partials (may be NULL when
+ * mvae_gemm_nt_workspace() returns 0).
+ */
+size_t mvae_gemm_nt_workspace(int M, int N, int K, int dtype_ab);
+int mvae_gemm_nt(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                 void* C, int64_t ldc, int dtype_c, const float* bias, int act, int accumulate,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Data movement helpers.
+ */
+/* dst[r, c] = (Td) src[r, c] for r<R, c<C; columns C..ldd-1 of dst are zeroed.  When dstT != NULL also
+ * dstT[c, r] = (Td) src[r, c] with columns R..ldt-1 zeroed.  Weight packing (fp32 master -> bf16 shadow and
+ * its transpose) and activation transposes. */
+int mvae_cast_transpose(int dtype_src, int dtype_dst, int R, int C, const void* src, int64_t lds_,
+                        void* dst, int64_t ldd, void* dstT, int64_t ldt, void* stream);
+
+/* out[n, b, a] = in[n, a, b] (fp32): the channel-major Flatten of models.py:6-10 <-> the conv GEMM's row order. */
+int mvae_permute021(int N, int A, int Bd, const float* in, float* out, void* stream);
+
+/* out[(t*B + b), :] = table[idx[b*L + t], :]   (fp32, W columns).  models.py:127 nn.Embedding, fused with the
+ * layer-0 input projection: table = E . W_ih0^T + b. */
+int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float* table, int W, float* out, void* stream);
+/* dtable[c, :] = sum over (t,b) with idx[b*L+t]==c of d[(t*B+b), :]   (deterministic).  d has dtype `dtype`. */
+int mvae_scatter_rows_tb(int dtype, const int64_t* idx, int B, int L, int nrows, const void* d, int64_t ldd, int W,
+                         float* dtable, void* ws, size_t ws_bytes, void* stream);
+size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Recurrent stack (K2, K7, K10, K12 of SURVEY.md): torch.nn.LSTM / nn.GRU, batch-major module semantics,
+ * zero (LSTM) or given (GRU) initial state, time-major storage here.  Replaces models.py:128, models.py:164,
+ * mosesvae.py:153, mosesvae.py:188.
+ *
+ * Schedule: layer-wavefront.  Launch d updates every cell (layer l, time t = d - l); one launch computes, for
+ * up to `layers` cells,   pre = x_t . W_ih^T + h_{t-1} . W_hh^T + bias   (two K-segments of one MFMA tile
+ * loop) and applies the gate non-linearities and the state update in the epilogue.
+ *
+ * Layer 0 input is either a real sequence x0 [T*B, in0] (dtype) or a precomputed fp32 pre-activation
+ * addend add0 (row (t*B+b) at add0 + t*add0_tstride + b*G*H; tstride 0 = time-invariant input, models.py:163
+ * Repeat), or both.  bias[l] (fp32 [G*H]) is added for layers whose input is a real sequence.
+ *
+ * Saved for backward (all caller-allocated):
+ *   hs[l]    [T][B][ldh]   dtype   layer outputs h_t          (hs[layers-1] is the stack output)
+ *   hsT[l]   [H][ldT]      dtype   the same transposed, column t*B+b  (may be NULL: not written)
+ *   cs[l]    [T][B][H]     fp32    cell states (LSTM only)
+ *   gates[l] [T][B][G*H]   dtype   post-activation gates i,f,g,o (LSTM) / r,z,n,(W_hn h + b_hn) (GRU)
+ * lengths (GRU path): per-sequence valid length, sorted descending (pack_sequence semantics: a finished
+ * sequence keeps its last state and emits zeros); NULL = all T.
+ */
+typedef struct {
+  int cell, dtype, layers, T, B, H, in0;
+  const void* x0; int64_t x0_ld;
+  const float* add0; int64_t add0_tstride;
+  const void* w_ih[MVAE_MAX_LAYERS]; int64_t ldw_ih[MVAE_MAX_LAYERS];   /* [G*H, in] (w_ih[0] unused when x0 == NULL) */
+  const void* w_hh[MVAE_MAX_LAYERS]; int64_t ldw_hh[MVAE_MAX_LAYERS];   /* [G*H, H] */
+  const float* bias[MVAE_MAX_LAYERS];                                    /* LSTM: b_ih+b_hh [4H]; GRU: [b_ir+b_hr; b_iz+b_hz; b_in; b_hn] [4H] */
+  const void* h0[MVAE_MAX_LAYERS]; int64_t ldh0;                         /* optional initial hidden state [B, ldh0] dtype (NULL = zeros) */
+  const int32_t* lengths;
+  void* hs[MVAE_MAX_LAYERS]; int64_t ldh;
+  void* hsT[MVAE_MAX_LAYERS]; int64_t ldT;
+  float* cs[MVAE_MAX_LAYERS];
+  void* gates[MVAE_MAX_LAYERS];
+} mvae_rnn_fwd_desc;
+
+int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
+
+/* Backward through time of the same stack (reverse wavefront).  One launch computes, per cell,
+ *   dh_t = dG^{l}_{t+1} . W_hh + dG^{l+1}_t . W_ih^{l+1} (+ dy_t for the top layer)
+ * and, in the epilogue, the gate derivative dG^{l}_t (pre-activation gradient) and dc_{t-1}.
+ *   w_hhT[l] [H, G*H], w_ihT[l] [in, G*H]: TRANSPOSED weights (K-contiguous for this contraction).
+ *   dy       [T][B][H] fp32 gradient w.r.t. the stack output (row stride dy_ld).
+ *   dG[l]    [T][B][G*H] dtype  (out)  pre-activation gradients; dG[0] is also the gradient of add0.
+ *   dGT[l]   [G*H][ldT]  dtype  (out, may be NULL)  transposed copy feeding the weight-gradient GEMMs
+ *                               (GRU: dGT holds the W_ih-side gradient rows [r,z,n]; dGhT the W_hh-side).
+ *   dcs      2*layers fp32 [B,H] scratch (ping-pong dc), dh_carry: GRU scratch.
+ * Weight / bias / input gradients are then plain mvae_gemm_nt / mvae_rowsum calls on dGT, hsT.
+ */
+typedef struct {
+  int cell, dtype, layers, T, B, H;
+  const void* w_hhT[MVAE_MAX_LAYERS]; int64_t ldw_hhT[MVAE_MAX_LAYERS];
+  const void* w_ihT[MVAE_MAX_LAYERS]; int64_t ldw_ihT[MVAE_MAX_LAYERS];   /* w_ihT[0] unused */
+  const int32_t* lengths;
+  const float* dy; int64_t dy_ld;
+  const float* dh_last[MVAE_MAX_LAYERS];                                  /* optional fp32 [B,H] gradient w.r.t. the final hidden state */
+  const void* hs[MVAE_MAX_LAYERS]; int64_t ldh;
+  const void* h0[MVAE_MAX_LAYERS]; int64_t ldh0;
+  const float* cs[MVAE_MAX_LAYERS];
+  const void* gates[MVAE_MAX_LAYERS];
+  void* dG[MVAE_MAX_LAYERS];
+  void* dGT[MVAE_MAX_LAYERS]; int64_t ldT;
+  void* dGh[MVAE_MAX_LAYERS]; void* dGhT[MVAE_MAX_LAYERS];               /* GRU only */
+  float* dstate[MVAE_MAX_LAYERS];                                         /* fp32 [2][B][H] ping-pong: LSTM dc, GRU dh carry */
+  float* dh0[MVAE_MAX_LAYERS];                                            /* optional out: gradient w.r.t. h0 (GRU decoder_lat path) */
+} mvae_rnn_bwd_desc;
+
+int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream);
+
+/* out[r] = sum_c X[r, c]  (X dtype, fp32 out; one wave per row, fixed order): bias gradients from dGT. */
+int mvae_rowsum(int dtype, int R, int C, const void* X, int64_t ldx, float* out, int accumulate, void* stream);
+/* out[b, :] = sum_t X[t, b, :]  (fp32 out): gradient of a time-invariant layer-0 input (models.py:163). */
+int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void* stream);
+/* out[n] = sum_m X[m, n] (fp32 in/out, deterministic): bias gradients of the dense / conv layers. */
+int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Conv1d(k) + bias + SELU, valid, stride 1 (K3; models.py:71-77 ConvSELU, :118-120, :129-131) as an
+ * im2col + MFMA GEMM with fused bias+SELU.  Input addressed by strides so the LSTM's time-major output can
+ * be consumed in place:  x[b, ci, w] = x[b*sb + ci*sc + w*sw].  Output y[(b*Wout + w), co] (ldy).
+ * col: scratch [B*Wout, Cin*k] fp32, kept for the backward pass.
+ */
+size_t mvae_conv1d_selu_fwd_workspace(int B, int Cin, int W, int Cout, int k);
+int mvae_conv1d_selu_fwd(int B, int Cin, int W, int Cout, int k, const float* x, int64_t sb, int64_t sc, int64_t sw,
+                         const float* w /* [Cout, Cin*k] */, const float* bias, float* col, float* y, int64_t ldy,
+                         void* ws, size_t ws_bytes, void* stream);
+/* dy [B*Wout, Cout] (gradient w.r.t. y; overwritten with the pre-activation gradient), y: forward output.
+ * dw [Cout, Cin*k], db [Cout], dx written with the same strides as x was read (dx_sb, dx_sc, dx_sw).
+ * wT [Cin*k, ldwT] transposed weights (ldwT >= Cout; Cout must be a multiple of 4);
+ * ws: scratch >= mvae_conv1d_selu_bwd_workspace bytes. */
+size_t mvae_conv1d_selu_bwd_workspace(int B, int Cin, int W, int Cout, int k);
+int mvae_conv1d_selu_bwd(int B, int Cin, int W, int Cout, int k, float* dy, int64_t lddy, const float* y, int64_t ldy,
+                         const float* col, const float* wT, int64_t ldwT, float* dw, float* db,
+                         float* dx, int64_t dx_sb, int64_t dx_sc, int64_t dx_sw, void* ws, size_t ws_bytes, void* stream);
+
+/* dpre = dy * SELU'(pre) expressed through the forward OUTPUT y (in place on dy).  models.py:58-68. */
+int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Lambda / reparameterisation (K5; models.py:80-94).  mulv [B, 2*o]: mu | log_var (one stacked GEMM).
+ * z = mu + exp(log_var/2) * eps        eps [B,o] is the already scaled noise (reference: 1e-2 * randn).
+ * Backward: dmulv[:, :o] = dmu + dz ; dmulv[:, o:] = dlogvar + dz * eps * 0.5 * exp(log_var/2).
+ */
+int mvae_lambda_fwd(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar, void* stream);
+int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const float* dz, const float* dmu,
+                    const float* dlogvar, float* dmulv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Output head (K8; models.py:157 Linear + nn.Softmax() over the class axis of the [B*L, C] view,
+ * models.py:43-50).  logits [(t*B+b), ldl] fp32 -> recon [B, L, C] fp32 probabilities.
+ * Backward: dlogits = p * (drecon - sum_c drecon*p), written in dtype as dl [(t*B+b), ldd] (zero padded
+ * columns C..ldd-1) and transposed dlT [Cpad][ldT] (column t*B+b).
+ */
+int mvae_softmax_tb_fwd(int B, int L, int C, const float* logits, int64_t ldl, float* recon, void* stream);
+int mvae_softmax_tb_bwd(int dtype, int B, int L, int C, const float* recon, const float* drecon,
+                        void* dl, int64_t ldd, void* dlT, int64_t ldT, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * ELBO of train.py:31-38, verbatim: max_len * BCELoss(mean)(recon, x) - 0.5*mean(1 + mu - logvar^2 - exp(mu))
+ * (binary CE on the softmax outputs with the log clamp at -100; mu / logvar swapped in the KL term, as the
+ * reference computes it).  loss_out[0] = total, [1] = xent term, [2] = KL term.  Deterministic two-stage
+ * reduction; ws >= mvae_bce_kl_loss_workspace().
+ * Backward: drecon = g*(max_len/n)*(p - t)/max(p(1-p),1e-12); dmu = g*(-0.5/m)(1 - exp(mu));
+ * dlogvar = g*(0.5/m)*2*logvar, with g = *grad_out (device scalar) or 1 when NULL.
+ */
+size_t mvae_bce_kl_loss_workspace(int64_t n_recon, int64_t n_latent);
+int mvae_bce_kl_loss_fwd(int64_t n_recon, const float* recon, const float* target, int64_t n_latent, const float* mu,
+                         const float* logvar, float max_len, float* loss_out, void* ws, size_t ws_bytes, void* stream);
+int mvae_bce_kl_loss_bwd(int64_t n_recon, const float* recon, const float* target, int64_t n_latent, const float* mu,
+                         const float* logvar, float max_len, const float* grad_out, float* drecon, float* dmu,
+                         float* dlogvar, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Optimiser surface (K14 + K15): torch.nn.utils.clip_grad_norm_(params, max_norm) (train.py:102) followed by
+ * torch.optim.Adam.step() (train.py:81,104) on a FLAT fp32 parameter / gradient / m / v buffer.
+ *   mvae_sumsq: partial[i] = sum of squares of chunk i (deterministic); norm_out[0] = sqrt(total) is
+ *   produced on device by mvae_clip_adam itself from `partial` (no host synchronisation).
+ *   coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping); grads are scaled by
+ *   grad_scale first (1/world_size after an all-reduce SUM).
+ */
+size_t mvae_sumsq_workspace(int64_t n);
+int mvae_sumsq(int64_t n, const float* g, float* partial, void* stream);
+int mvae_clip_adam(int64_t n, float* p, const float* g, float* m, float* v, const float* partial, int64_t npartial,
+                   float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                   float* norm_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVAE_H_ */

@@ -1,0 +1,14 @@
+"""MI355X-native SMILES-VAE training hot path (drop-in for aclyde11/molecular-VAE's models.py / train.py surface).
+
+The directory name (``molecular-vae_amd``) is fixed by the repo layout contract and is not a Python identifier;
+import it through the ``molecular_vae_amd`` alias package at the repo root.
+"""
+from . import _lib  # noqa: F401
+from .models import (MolecularVAE, MolEncoder, MolDecoder, Lambda, ConvSELU, SELU, TimeDistributed, Repeat,  # noqa: F401
+                     Flatten)
+from .functional import bce_kl_loss, make_loss_function  # noqa: F401
+from .train import FusedAdam, GradSync, ShardedSampler, shard_batch, train_step, exact_match_accuracy  # noqa: F401
+
+__all__ = ["MolecularVAE", "MolEncoder", "MolDecoder", "Lambda", "ConvSELU", "SELU", "TimeDistributed", "Repeat",
+           "Flatten", "bce_kl_loss", "make_loss_function", "FusedAdam", "GradSync", "ShardedSampler", "shard_batch",
+           "train_step", "exact_match_accuracy"]

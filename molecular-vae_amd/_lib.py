@@ -1,0 +1,140 @@
+"""ctypes binding of libmvae_hip.so (C ABI in include/mvae.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvae_hip.so")
+
+MVAE_F32, MVAE_BF16 = 0, 1
+ACT_NONE, ACT_SELU = 0, 1
+CELL_LSTM, CELL_GRU = 0, 1
+MAX_LAYERS = 8
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class RnnFwdDesc(C.Structure):
+    _fields_ = [("cell", _i), ("dtype", _i), ("layers", _i), ("T", _i), ("B", _i), ("H", _i), ("in0", _i),
+                ("x0", _vp), ("x0_ld", _i64), ("add0", _vp), ("add0_tstride", _i64),
+                ("w_ih", _vp * MAX_LAYERS), ("ldw_ih", _i64 * MAX_LAYERS),
+                ("w_hh", _vp * MAX_LAYERS), ("ldw_hh", _i64 * MAX_LAYERS),
+                ("bias", _vp * MAX_LAYERS),
+                ("h0", _vp * MAX_LAYERS), ("ldh0", _i64),
+                ("lengths", _vp),
+                ("hs", _vp * MAX_LAYERS), ("ldh", _i64),
+                ("hsT", _vp * MAX_LAYERS), ("ldT", _i64),
+                ("cs", _vp * MAX_LAYERS),
+                ("gates", _vp * MAX_LAYERS)]
+
+
+class RnnBwdDesc(C.Structure):
+    _fields_ = [("cell", _i), ("dtype", _i), ("layers", _i), ("T", _i), ("B", _i), ("H", _i),
+                ("w_hhT", _vp * MAX_LAYERS), ("ldw_hhT", _i64 * MAX_LAYERS),
+                ("w_ihT", _vp * MAX_LAYERS), ("ldw_ihT", _i64 * MAX_LAYERS),
+                ("lengths", _vp),
+                ("dy", _vp), ("dy_ld", _i64),
+                ("dh_last", _vp * MAX_LAYERS),
+                ("hs", _vp * MAX_LAYERS), ("ldh", _i64),
+                ("h0", _vp * MAX_LAYERS), ("ldh0", _i64),
+                ("cs", _vp * MAX_LAYERS),
+                ("gates", _vp * MAX_LAYERS),
+                ("dG", _vp * MAX_LAYERS),
+                ("dGT", _vp * MAX_LAYERS), ("ldT", _i64),
+                ("dGh", _vp * MAX_LAYERS), ("dGhT", _vp * MAX_LAYERS),
+                ("dstate", _vp * MAX_LAYERS),
+                ("dh0", _vp * MAX_LAYERS)]
+
+
+# name -> (restype, argtypes); mirrors include/mvae.h one to one (tests check every symbol is exported)
+SIGNATURES = {
+    "mvae_abi_version": (_i, []),
+    "mvae_status_string": (C.c_char_p, [_i]),
+    "mvae_gemm_nt_workspace": (_sz, [_i, _i, _i, _i]),
+    "mvae_gemm_nt": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "mvae_cast_transpose": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "mvae_permute021": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "mvae_gather_rows_tb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
+    "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
+    "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
+    "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),
+    "mvae_rowsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp]),
+    "mvae_timesum": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "mvae_colsum": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
+    "mvae_conv1d_selu_fwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "mvae_conv1d_selu_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "mvae_conv1d_selu_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "mvae_conv1d_selu_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64,
+                                  _vp, _sz, _vp]),
+    "mvae_selu_bwd": (_i, [_i64, _vp, _vp, _vp]),
+    "mvae_lambda_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_lambda_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_softmax_tb_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp]),
+    "mvae_softmax_tb_bwd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "mvae_bce_kl_loss_workspace": (_sz, [_i64, _i64]),
+    "mvae_bce_kl_loss_fwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
+    "mvae_bce_kl_loss_bwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_sumsq_workspace": (_sz, [_i64]),
+    "mvae_sumsq": (_i, [_i64, _vp, _vp, _vp]),
+    "mvae_clip_adam": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MvaeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvaeError(
+            f"{LIB_PATH} not found: build it with molecular-vae_amd/csrc/build.sh "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvae_abi_version() != 1:
+        raise MvaeError("libmvae_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mvae_status_string(rc).decode()
+        raise MvaeError(f"{what or 'mvae call'} failed: {rc} ({msg})")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return MVAE_F32
+    if dtype == torch.bfloat16:
+        return MVAE_BF16
+    raise MvaeError(f"unsupported dtype {dtype}")
+
+
+# bumped by in-place parameter updates that bypass torch's version counters (FusedAdam) so that the
+# packed (bf16 / transposed) weight shadows are refreshed
+PARAM_EPOCH = [0]

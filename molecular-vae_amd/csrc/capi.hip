@@ -1,0 +1,32 @@
+// extern "C" entry points that are thin wrappers over the launchers in gemm.hip / rnn.hip.
+#include "common.hpp"
+#include "kernels.hpp"
+
+int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st);
+int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st);
+
+extern "C" {
+
+int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+
+const char* mvae_status_string(int status) {
+  switch (status) {
+    case MVAE_OK: return "ok";
+    case MVAE_ERR_INVALID: return "invalid argument";
+    case MVAE_ERR_WORKSPACE: return "workspace too small";
+    case MVAE_ERR_UNSUPPORTED: return "unsupported combination";
+    default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
+  }
+}
+
+size_t mvae_gemm_nt_workspace(int M, int N, int K, int dtype_ab) { return gemm_nt_workspace_bytes(M, N, K, dtype_ab); }
+
+int mvae_gemm_nt(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                 int dtype_c, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  return launch_gemm_nt(dtype_ab, M, N, K, A, lda, B, ldb, C, ldc, dtype_c, bias, act, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) { return rnn_fwd_impl(d, (hipStream_t)stream); }
+int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the SMILES-VAE training path.
+// Wave = 64 lanes; MFMA 16x16 tiles; LDS tiles of 128-byte rows with a 16-byte-chunk XOR swizzle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvae.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+struct bf16_t { uint16_t x; };   // storage-only bf16
+
+#define MVAE_CHECK_HIP(expr)                         \
+  do {                                               \
+    hipError_t _e = (expr);                          \
+    if (_e != hipSuccess) return (int)_e;            \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+  static constexpr int EPC = 4;            // elements per 16-byte chunk
+  static constexpr int DT = MVAE_F32;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct TT<bf16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int DT = MVAE_BF16;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(p->x); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { p->x = f2bf(v); }
+};
+
+// One 16x16 output tile update from a 16-byte A chunk and a 16-byte B chunk per lane.
+// Lane l supplies row/col (l & 15) and the k-slice (l >> 4) of a 64-byte-wide K block:
+//   bf16: 8 elements -> one v_mfma_f32_16x16x32_bf16  (A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15])
+//   f32 : 4 elements -> four v_mfma_f32_16x16x4_f32; MFMA #i consumes element i of every lane, i.e.
+//         k = 4*(l>>4)+i in both operands (a permutation of k, which a dot product does not see).
+// C/D layout (both): col = l & 15, row = 4*(l>>4) + reg.
+template <typename T> __device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& c);
+template <> __device__ __forceinline__ void mma16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(const uint4& a, const uint4& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+}
+
+// LDS tile: rows of KB = 128 bytes = 8 chunks of 16 bytes; chunk index XOR (row & 7) makes the
+// ds_read_b128 fragment reads (16 rows x one chunk column per 16-lane group) bank-conflict free.
+constexpr int KB = 128;
+__device__ __forceinline__ int swz(int row, int chunk) { return row * KB + (((chunk ^ row) & 7) << 4); }
+
+constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
+constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
+__device__ __forceinline__ float selu_f(float x) { return x > 0.f ? SELU_SCALE * x : SELU_SCALE * SELU_ALPHA * expm1f(x); }
+// derivative expressed through the OUTPUT y = selu(x):  x>0 -> scale ; else y + scale*alpha
+__device__ __forceinline__ float selu_grad_from_out(float y) { return y > 0.f ? SELU_SCALE : y + SELU_SCALE * SELU_ALPHA; }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// deterministic block sum (256 threads); result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}

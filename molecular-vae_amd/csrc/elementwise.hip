@@ -1,0 +1,528 @@
+// HBM-bound helper kernels of the SMILES-VAE training path (gfx950): casts/transposes, embedding-table gather and
+// its deterministic scatter, im2col/col2im, SELU derivative, reparameterisation, softmax head, ELBO, reductions,
+// gradient-norm + Adam.  All reductions use fixed orders (wave shuffle -> LDS -> serial over blocks) so results
+// are bitwise reproducible run to run.
+#include "common.hpp"
+#include "kernels.hpp"
+
+static inline int grid_for(long n, int per_block = 256, int cap = 2048) {
+  long b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------- cast / transpose
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(int R, int C, const TS* src, long lds_, TD* dst, long ldd, TD* dstT, long ldt) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + i * 8, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) v = TT<TS>::ld(src + (long)r * lds_ + c);
+    tile[ty + i * 8][tx] = v;
+    if (dst && r < R && c < ldd) TT<TD>::st(dst + (long)r * ldd + c, v);   // zero fill of the pad columns
+  }
+  if (!dstT) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + i * 8, r = r0 + tx;     // dstT[c][r]
+    if (c < C && r < ldt) TT<TD>::st(dstT + (long)c * ldt + r, tile[tx][ty + i * 8]);
+  }
+}
+
+int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, long lds_, void* dst, long ldd, void* dstT,
+                          long ldt, hipStream_t st) {
+  if (R <= 0 || C <= 0) return MVAE_OK;
+  if (!src || (!dst && !dstT)) return MVAE_ERR_INVALID;
+  if (dst && ldd < C) return MVAE_ERR_INVALID;
+  if (dstT && ldt < R) return MVAE_ERR_INVALID;
+  const long cmax = (dst && ldd > C) ? ldd : C;     // cover pad columns of dst
+  const long rmax = (dstT && ldt > R) ? ldt : R;    // cover pad columns of dstT
+  dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32)), block(256);
+  if (dsrc == MVAE_F32 && ddst == MVAE_F32)
+    hipLaunchKernelGGL((cast_transpose_kernel<float, float>), grid, block, 0, st, R, C, (const float*)src, lds_, (float*)dst, ldd, (float*)dstT, ldt);
+  else if (dsrc == MVAE_F32 && ddst == MVAE_BF16)
+    hipLaunchKernelGGL((cast_transpose_kernel<float, bf16_t>), grid, block, 0, st, R, C, (const float*)src, lds_, (bf16_t*)dst, ldd, (bf16_t*)dstT, ldt);
+  else if (dsrc == MVAE_BF16 && ddst == MVAE_BF16)
+    hipLaunchKernelGGL((cast_transpose_kernel<bf16_t, bf16_t>), grid, block, 0, st, R, C, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, (bf16_t*)dstT, ldt);
+  else if (dsrc == MVAE_BF16 && ddst == MVAE_F32)
+    hipLaunchKernelGGL((cast_transpose_kernel<bf16_t, float>), grid, block, 0, st, R, C, (const bf16_t*)src, lds_, (float*)dst, ldd, (float*)dstT, ldt);
+  else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------- embedding table
+__global__ __launch_bounds__(256) void gather_rows_tb_kernel(const int64_t* idx, int B, int L, int nrows, const float* table, int W, float* out) {
+  const long n = (long)B * L * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / W; const int c = (int)(i - row * W);
+    const int t = (int)(row / B), b = (int)(row - (long)t * B);
+    long id = idx[(long)b * L + t];
+    id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
+    out[i] = table[id * W + c];
+  }
+}
+
+// stage 1: block k owns rows [k*RPB, (k+1)*RPB) of d; thread j owns column j; LDS table [nrows][W] (per-thread column => no races).
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_tb_stage1(const int64_t* idx, int B, int L, int nrows, const T* d, long ldd, int W,
+                                                              int rpb, float* partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tab = reinterpret_cast<float*>(smem_raw);   // [nrows][W]
+  const long total = (long)B * L;
+  for (int i = threadIdx.x; i < nrows * W; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const long rbeg = (long)blockIdx.x * rpb;
+  long rend = rbeg + rpb; if (rend > total) rend = total;
+  for (int c = threadIdx.x; c < W; c += 256) {
+    for (long row = rbeg; row < rend; ++row) {
+      const int t = (int)(row / B), b = (int)(row - (long)t * B);
+      long id = idx[(long)b * L + t];
+      id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
+      tab[id * W + c] += TT<T>::ld(d + row * ldd + c);
+    }
+  }
+  __syncthreads();
+  float* out = partial + (long)blockIdx.x * nrows * W;
+  for (int i = threadIdx.x; i < nrows * W; i += 256) out[i] = tab[i];
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial, int nparts, long n, float* out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int k = 0; k < nparts; ++k) v += partial[(long)k * n + i];
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- im2col / col2im
+// col[(b*Wout + w), ci*k + kk] = x[b*sb + ci*sc + (w+kk)*sw]
+__global__ __launch_bounds__(256) void im2col_kernel(int B, int Cin, int W, int k, const float* x, long sb, long sc, long sw, float* col) {
+  const int Wout = W - k + 1;
+  const long K = (long)Cin * k, n = (long)B * Wout * K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / K; const int kc = (int)(i - row * K);
+    const int b = (int)(row / Wout), w = (int)(row - (long)b * Wout);
+    const int ci = kc / k, kk = kc - ci * k;
+    col[i] = x[(long)b * sb + (long)ci * sc + (long)(w + kk) * sw];
+  }
+}
+// dx[b, ci, p] = sum_{kk} dcol[(b*Wout + p-kk), ci*k + kk]  for 0 <= p-kk < Wout  (gather form: deterministic)
+__global__ __launch_bounds__(256) void col2im_kernel(int B, int Cin, int W, int k, const float* dcol, float* dx, long sb, long sc, long sw) {
+  const int Wout = W - k + 1;
+  const long K = (long)Cin * k, n = (long)B * Cin * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int p = (int)(i % W); const long bc = i / W; const int ci = (int)(bc % Cin); const int b = (int)(bc / Cin);
+    float v = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+      const int w = p - kk;
+      if (w >= 0 && w < Wout) v += dcol[((long)b * Wout + w) * K + (long)ci * k + kk];
+    }
+    dx[(long)b * sb + (long)ci * sc + (long)p * sw] = v;
+  }
+}
+
+// out[n, b, a] = in[n, a, b]   (batched 2-D transpose; flatten order of models.py:6-10 <-> GEMM row order)
+__global__ __launch_bounds__(256) void permute021_kernel(int N, int A, int Bd, const float* in, float* out) {
+  const long n = (long)N * A * Bd;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int a = (int)(i % A); const long nb = i / A; const int b = (int)(nb % Bd); const long nn = nb / Bd;
+    out[i] = in[(nn * A + a) * Bd + b];
+  }
+}
+
+__global__ __launch_bounds__(256) void selu_bwd_kernel(long n, float* dy, const float* y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dy[i] *= selu_grad_from_out(y[i]);
+}
+int launch_selu_bwd(long n, float* dy, const float* y, hipStream_t st) {
+  if (n <= 0) return MVAE_OK;
+  hipLaunchKernelGGL(selu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, dy, y);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------- reductions
+// out[n] = sum_m X[m, n]: block = 64 columns x 4 row-groups; fixed order.
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* X, long ldx, float* out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float v = 0.f;
+  if (c < N) for (int m = g; m < M; m += 4) v += X[(long)m * ldx + c];
+  red[g][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (g == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+int launch_colsum(int M, int N, const float* X, long ldx, float* out, hipStream_t st) {
+  if (N <= 0) return MVAE_OK;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, M, N, X, ldx, out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+// out[r] (+)= sum_c X[r, c]: one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(int R, int C, const T* X, long ldx, float* out, int accumulate) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const T* p = X + (long)r * ldx;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) v += TT<T>::ld(p + c);
+  v = wave_sum(v);
+  if (lane == 0) out[r] = accumulate ? out[r] + v : v;
+}
+// out[b, w] = sum_t X[t, b, w]
+template <typename T>
+__global__ __launch_bounds__(256) void timesum_kernel(int T_, long BW, const T* X, float* out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < BW; i += (long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int t = 0; t < T_; ++t) v += TT<T>::ld(X + (long)t * BW + i);
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- Lambda (models.py:80-94)
+__global__ __launch_bounds__(256) void lambda_fwd_kernel(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar) {
+  const long n = (long)B * o;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / o; const int c = (int)(i - b * o);
+    const float m = mulv[b * 2 * o + c], lv = mulv[b * 2 * o + o + c];
+    mu[i] = m; logvar[i] = lv;
+    z[i] = m + expf(lv * 0.5f) * eps[i];
+  }
+}
+__global__ __launch_bounds__(256) void lambda_bwd_kernel(int B, int o, const float* mulv, const float* eps, const float* dz, const float* dmu,
+                                                         const float* dlogvar, float* dmulv) {
+  const long n = (long)B * o;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / o; const int c = (int)(i - b * o);
+    const float lv = mulv[b * 2 * o + o + c];
+    const float g = dz ? dz[i] : 0.f;
+    dmulv[b * 2 * o + c] = (dmu ? dmu[i] : 0.f) + g;
+    dmulv[b * 2 * o + o + c] = (dlogvar ? dlogvar[i] : 0.f) + g * eps[i] * 0.5f * expf(lv * 0.5f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- softmax head
+// one wave per (t,b) row; C <= 64*4
+__global__ __launch_bounds__(256) void softmax_tb_fwd_kernel(int B, int L, int C, const float* logits, long ldl, float* recon) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)B * L) return;
+  const int t = (int)(row / B), b = (int)(row - (long)t * B);
+  const float* x = logits + row * ldl;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(x[c] - mx);
+  s = wave_sum(s);
+  float* out = recon + ((long)b * L + t) * C;
+  for (int c = lane; c < C; c += 64) out[c] = expf(x[c] - mx) / s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_tb_bwd_kernel(int B, int L, int C, const float* recon, const float* drecon, T* dl, long ldd,
+                                                             T* dlT, long ldT) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)B * L) return;
+  const int t = (int)(row / B), b = (int)(row - (long)t * B);
+  const float* p = recon + ((long)b * L + t) * C;
+  const float* dp = drecon + ((long)b * L + t) * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += dp[c] * p[c];
+  s = wave_sum(s);
+  for (int c = lane; c < ldd; c += 64) {
+    const float v = (c < C) ? p[c] * (dp[c] - s) : 0.f;
+    TT<T>::st(dl + row * ldd + c, v);
+    if (dlT && c < C) TT<T>::st(dlT + (long)c * ldT + row, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- ELBO (train.py:31-38)
+constexpr int LOSS_BLOCKS = 512;
+__global__ __launch_bounds__(256) void bce_kl_partial_kernel(long n, const float* recon, const float* target, long m, const float* mu,
+                                                             const float* logvar, float* partial) {
+  __shared__ float red[4];
+  float a = 0.f, k = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float p = recon[i], t = target[i];
+    const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);   // BCELoss clamps both logs at -100
+    a -= t * lp + (1.f - t) * l1p;
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long)gridDim.x * 256) {
+    const float u = mu[i], v = logvar[i];
+    k += 1.f + u - v * v - expf(u);                                             // mu / logvar swapped, as train.py:36-37
+  }
+  a = block_sum_256(a, red);
+  k = block_sum_256(k, red);
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = k; }
+}
+__global__ __launch_bounds__(64) void bce_kl_final_kernel(int nblocks, const float* partial, long n, long m, float max_len, float* out) {
+  float a = 0.f, k = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { a += partial[2 * i]; k += partial[2 * i + 1]; }
+  a = wave_sum(a); k = wave_sum(k);
+  if (threadIdx.x == 0) {
+    const float xent = max_len * (a / (float)n);
+    const float kl = -0.5f * (k / (float)m);
+    out[0] = xent + kl; out[1] = xent; out[2] = kl;
+  }
+}
+__global__ __launch_bounds__(256) void bce_kl_bwd_kernel(long n, const float* recon, const float* target, long m, const float* mu,
+                                                         const float* logvar, float max_len, const float* grad_out, float* drecon,
+                                                         float* dmu, float* dlogvar) {
+  const float g = grad_out ? grad_out[0] : 1.f;
+  const float sr = g * max_len / (float)n, sl = g * (-0.5f) / (float)m;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float p = recon[i], t = target[i];
+    drecon[i] = sr * (p - t) / fmaxf((1.f - p) * p, 1e-12f);
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long)gridDim.x * 256) {
+    if (dmu) dmu[i] = sl * (1.f - expf(mu[i]));
+    if (dlogvar) dlogvar[i] = sl * (-2.f * logvar[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- grad-norm + Adam
+constexpr int SUMSQ_CHUNK = 1 << 16;   // elements per partial
+__global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g, float* partial) {
+  __shared__ float red[4];
+  const long beg = (long)blockIdx.x * SUMSQ_CHUNK;
+  long end = beg + SUMSQ_CHUNK; if (end > n) end = n;
+  float a = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) { const float v = g[i]; a += v * v; }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(256) void clip_adam_kernel(long n, float* p, const float* g, float* m, float* v, const float* partial, long npartial,
+                                                        float grad_scale, float max_norm, float lr, float b1, float b2, float eps,
+                                                        float bc1, float bc2_sqrt, float* norm_out) {
+  __shared__ float red[4];
+  __shared__ float s_coef;
+  // every block re-derives the global norm from the partials in the same fixed order
+  float a = 0.f;
+  for (long i = threadIdx.x; i < npartial; i += 256) a += partial[i];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(a) * grad_scale;
+    float coef = 1.f;
+    if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); if (coef > 1.f) coef = 1.f; }
+    s_coef = coef * grad_scale;
+    if (blockIdx.x == 0 && norm_out) norm_out[0] = norm;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- extern "C" surface
+extern "C" {
+
+int mvae_cast_transpose(int dtype_src, int dtype_dst, int R, int C, const void* src, int64_t lds_, void* dst, int64_t ldd,
+                        void* dstT, int64_t ldt, void* stream) {
+  return launch_cast_transpose(dtype_src, dtype_dst, R, C, src, lds_, dst, ldd, dstT, ldt, (hipStream_t)stream);
+}
+
+int mvae_permute021(int N, int A, int Bd, const float* in, float* out, void* stream) {
+  if (!in || !out || N < 1 || A < 1 || Bd < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(permute021_kernel, dim3(grid_for((long)N * A * Bd)), dim3(256), 0, (hipStream_t)stream, N, A, Bd, in, out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float* table, int W, float* out, void* stream) {
+  if (!idx || !table || !out || B < 1 || L < 1 || W < 1 || nrows < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(gather_rows_tb_kernel, dim3(grid_for((long)B * L * W)), dim3(256), 0, (hipStream_t)stream, idx, B, L, nrows, table, W, out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+static int scatter_parts(int B, int L) { long rows = (long)B * L; long parts = (rows + 255) / 256; if (parts > 256) parts = 256; return (int)parts; }
+size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W) { return (size_t)scatter_parts(B, L) * nrows * W * sizeof(float); }
+int mvae_scatter_rows_tb(int dtype, const int64_t* idx, int B, int L, int nrows, const void* d, int64_t ldd, int W, float* dtable,
+                         void* ws, size_t ws_bytes, void* stream) {
+  if (!idx || !d || !dtable || B < 1 || L < 1 || W < 1 || nrows < 1) return MVAE_ERR_INVALID;
+  const size_t ldsb = (size_t)nrows * W * sizeof(float);
+  if (ldsb > 64 * 1024) return MVAE_ERR_UNSUPPORTED;
+  const int parts = scatter_parts(B, L);
+  if (!ws || ws_bytes < mvae_scatter_rows_tb_workspace(B, L, nrows, W)) return MVAE_ERR_WORKSPACE;
+  const long rows = (long)B * L;
+  const int rpb = (int)((rows + parts - 1) / parts);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MVAE_F32)
+    hipLaunchKernelGGL((scatter_rows_tb_stage1<float>), dim3(parts), dim3(256), ldsb, st, idx, B, L, nrows, (const float*)d, ldd, W, rpb, (float*)ws);
+  else if (dtype == MVAE_BF16)
+    hipLaunchKernelGGL((scatter_rows_tb_stage1<bf16_t>), dim3(parts), dim3(256), ldsb, st, idx, B, L, nrows, (const bf16_t*)d, ldd, W, rpb, (float*)ws);
+  else return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(grid_for((long)nrows * W)), dim3(256), 0, st, (const float*)ws, parts, (long)nrows * W, dtable);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+int mvae_rowsum(int dtype, int R, int C, const void* X, int64_t ldx, float* out, int accumulate, void* stream) {
+  if (!X || !out || R < 1) return MVAE_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MVAE_F32) hipLaunchKernelGGL((rowsum_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, st, R, C, (const float*)X, ldx, out, accumulate);
+  else if (dtype == MVAE_BF16) hipLaunchKernelGGL((rowsum_kernel<bf16_t>), dim3((R + 3) / 4), dim3(256), 0, st, R, C, (const bf16_t*)X, ldx, out, accumulate);
+  else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void* stream) {
+  if (!X || !out || T < 1 || B < 1 || W < 1) return MVAE_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const long BW = (long)B * W;
+  if (dtype == MVAE_F32) hipLaunchKernelGGL((timesum_kernel<float>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const float*)X, out);
+  else if (dtype == MVAE_BF16) hipLaunchKernelGGL((timesum_kernel<bf16_t>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
+  else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* stream) {
+  if (!X || !out || M < 0) return MVAE_ERR_INVALID;
+  return launch_colsum(M, N, X, ldx, out, (hipStream_t)stream);
+}
+int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream) {
+  if (!dy || !y) return MVAE_ERR_INVALID;
+  return launch_selu_bwd(n, dy, y, (hipStream_t)stream);
+}
+
+// ---- conv1d + SELU (models.py:71-77, 118-120, 129-131)
+size_t mvae_conv1d_selu_fwd_workspace(int B, int Cin, int W, int Cout, int k) {
+  return gemm_nt_workspace_bytes(B * (W - k + 1), Cout, Cin * k, MVAE_F32);
+}
+int mvae_conv1d_selu_fwd(int B, int Cin, int W, int Cout, int k, const float* x, int64_t sb, int64_t sc, int64_t sw, const float* w,
+                         const float* bias, float* col, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !w || !col || !y || B < 1 || Cin < 1 || Cout < 1 || k < 1 || W < k) return MVAE_ERR_INVALID;
+  if (((long)Cin * k) % 4) return MVAE_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int Wout = W - k + 1;
+  const long K = (long)Cin * k;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((long)B * Wout * K, 256, 8192)), dim3(256), 0, st, B, Cin, W, k, x, sb, sc, sw, col);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return launch_gemm_nt(MVAE_F32, B * Wout, Cout, (int)K, col, K, w, K, y, ldy, MVAE_F32, bias, MVAE_ACT_SELU, 0, ws, ws_bytes, st);
+}
+
+static inline long pad4(long x) { return (x + 3) & ~3L; }
+size_t mvae_conv1d_selu_bwd_workspace(int B, int Cin, int W, int Cout, int k) {
+  const long Wout = W - k + 1, M = (long)B * Wout, K = (long)Cin * k, Mp = pad4(M);
+  size_t dcol = (size_t)M * K * 4, dyT = (size_t)Cout * Mp * 4, colT = (size_t)K * Mp * 4;
+  size_t g = gemm_nt_workspace_bytes(Cout, (int)K, (int)Mp, MVAE_F32);
+  size_t g2 = gemm_nt_workspace_bytes((int)M, (int)K, Cout, MVAE_F32);
+  return dcol + dyT + colT + (g > g2 ? g : g2) + 256;
+}
+int mvae_conv1d_selu_bwd(int B, int Cin, int W, int Cout, int k, float* dy, int64_t lddy, const float* y, int64_t ldy, const float* col,
+                         const float* wT, int64_t ldwT, float* dw, float* db, float* dx, int64_t dx_sb, int64_t dx_sc, int64_t dx_sw,
+                         void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !y || !col || !wT || !dw || !db || !ws) return MVAE_ERR_INVALID;
+  if (lddy != ldy || lddy != Cout || (Cout & 3) || ldwT < Cout) return MVAE_ERR_INVALID;   // contiguous [M, Cout], Cout % 4 == 0
+  if (ws_bytes < mvae_conv1d_selu_bwd_workspace(B, Cin, W, Cout, k)) return MVAE_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const long Wout = W - k + 1, M = (long)B * Wout, K = (long)Cin * k, Mp = pad4(M);
+  char* wp = reinterpret_cast<char*>(ws);
+  float* dcol = reinterpret_cast<float*>(wp); wp += (size_t)M * K * 4;
+  float* dyT = reinterpret_cast<float*>(wp); wp += (size_t)Cout * Mp * 4;
+  float* colT = reinterpret_cast<float*>(wp); wp += (size_t)K * Mp * 4;
+  void* gws = wp; size_t gws_bytes = ws_bytes - (size_t)(wp - reinterpret_cast<char*>(ws));
+  int rc;
+  if ((rc = launch_selu_bwd(M * Cout, dy, y, st))) return rc;                                  // dy <- dpre
+  if ((rc = launch_colsum((int)M, Cout, dy, Cout, db, st))) return rc;
+  if ((rc = launch_cast_transpose(MVAE_F32, MVAE_F32, (int)M, Cout, dy, Cout, nullptr, 0, dyT, Mp, st))) return rc;
+  if ((rc = launch_cast_transpose(MVAE_F32, MVAE_F32, (int)M, (int)K, col, K, nullptr, 0, colT, Mp, st))) return rc;
+  // dw[Cout, K] = dpre^T . col
+  if ((rc = launch_gemm_nt(MVAE_F32, Cout, (int)K, (int)Mp, dyT, Mp, colT, Mp, dw, K, MVAE_F32, nullptr, 0, 0, gws, gws_bytes, st))) return rc;
+  if (dx) {
+    // dcol[M, K] = dpre[M, Cout] . w[Cout, K]  (B operand = w^T [K, ldwT])
+    if ((rc = launch_gemm_nt(MVAE_F32, (int)M, (int)K, Cout, dy, Cout, wT, ldwT, dcol, K, MVAE_F32, nullptr, 0, 0, gws, gws_bytes, st))) return rc;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)B * Cin * W, 256, 8192)), dim3(256), 0, st, B, Cin, W, k, dcol, dx, dx_sb, dx_sc, dx_sw);
+    MVAE_CHECK_HIP(hipGetLastError());
+  }
+  return MVAE_OK;
+}
+
+int mvae_lambda_fwd(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar, void* stream) {
+  if (!mulv || !eps || !z || !mu || !logvar || B < 1 || o < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(lambda_fwd_kernel, dim3(grid_for((long)B * o)), dim3(256), 0, (hipStream_t)stream, B, o, mulv, eps, z, mu, logvar);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const float* dz, const float* dmu, const float* dlogvar,
+                    float* dmulv, void* stream) {
+  if (!mulv || !eps || !dmulv || B < 1 || o < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(lambda_bwd_kernel, dim3(grid_for((long)B * o)), dim3(256), 0, (hipStream_t)stream, B, o, mulv, eps, dz, dmu, dlogvar, dmulv);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+int mvae_softmax_tb_fwd(int B, int L, int C, const float* logits, int64_t ldl, float* recon, void* stream) {
+  if (!logits || !recon || B < 1 || L < 1 || C < 1) return MVAE_ERR_INVALID;
+  const long rows = (long)B * L;
+  hipLaunchKernelGGL(softmax_tb_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, L, C, logits, ldl, recon);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_softmax_tb_bwd(int dtype, int B, int L, int C, const float* recon, const float* drecon, void* dl, int64_t ldd, void* dlT,
+                        int64_t ldT, void* stream) {
+  if (!recon || !drecon || !dl || B < 1 || L < 1 || C < 1 || ldd < C) return MVAE_ERR_INVALID;
+  const long rows = (long)B * L;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MVAE_F32)
+    hipLaunchKernelGGL((softmax_tb_bwd_kernel<float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, B, L, C, recon, drecon, (float*)dl, ldd, (float*)dlT, ldT);
+  else if (dtype == MVAE_BF16)
+    hipLaunchKernelGGL((softmax_tb_bwd_kernel<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, B, L, C, recon, drecon, (bf16_t*)dl, ldd, (bf16_t*)dlT, ldT);
+  else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+size_t mvae_bce_kl_loss_workspace(int64_t, int64_t) { return (size_t)LOSS_BLOCKS * 2 * sizeof(float); }
+int mvae_bce_kl_loss_fwd(int64_t n, const float* recon, const float* target, int64_t m, const float* mu, const float* logvar,
+                         float max_len, float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!recon || !target || !mu || !logvar || !loss_out || n < 1 || m < 1) return MVAE_ERR_INVALID;
+  if (!ws || ws_bytes < mvae_bce_kl_loss_workspace(n, m)) return MVAE_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bce_kl_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, (long)n, recon, target, (long)m, mu, logvar, (float*)ws);
+  hipLaunchKernelGGL(bce_kl_final_kernel, dim3(1), dim3(64), 0, st, LOSS_BLOCKS, (const float*)ws, (long)n, (long)m, max_len, loss_out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_bce_kl_loss_bwd(int64_t n, const float* recon, const float* target, int64_t m, const float* mu, const float* logvar,
+                         float max_len, const float* grad_out, float* drecon, float* dmu, float* dlogvar, void* stream) {
+  if (!recon || !target || !mu || !logvar || !drecon || n < 1 || m < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(bce_kl_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, recon, target, (long)m, mu, logvar, max_len,
+                     grad_out, drecon, dmu, dlogvar);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+size_t mvae_sumsq_workspace(int64_t n) { return (size_t)((n + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK) * sizeof(float); }
+int mvae_sumsq(int64_t n, const float* g, float* partial, void* stream) {
+  if (!g || !partial || n < 1) return MVAE_ERR_INVALID;
+  const int blocks = (int)((n + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)n, g, partial);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_clip_adam(int64_t n, float* p, const float* g, float* m, float* v, const float* partial, int64_t npartial, float grad_scale,
+                   float max_norm, float lr, float beta1, float beta2, float eps, int step, float* norm_out, void* stream) {
+  if (!p || !g || !m || !v || !partial || n < 1 || npartial < 1 || step < 1) return MVAE_ERR_INVALID;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (long)n, p, g, m, v, partial,
+                     (long)npartial, grad_scale, max_norm, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), norm_out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+}  // extern "C"

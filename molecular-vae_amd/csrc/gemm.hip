@@ -1,0 +1,166 @@
+// NT GEMM on MFMA for gfx950:  C[M,N] = act(A[M,K] . B[N,K]^T + bias[N]),  fp32 accumulate.
+// bf16 operands -> v_mfma_f32_16x16x32_bf16, f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32).
+// Tiles 128x128 or 64x64 per 256-thread workgroup, split-K with a deterministic fp32 slab reduction when the
+// output alone cannot fill 256 CUs.  Blocks are remapped so that consecutive tiles of one XCD share A rows.
+#include "tile.hpp"
+#include "kernels.hpp"
+
+struct GemmArgs {
+  const void* A; const void* B; void* C; const float* bias; float* partial;
+  long lda, ldb, ldc;
+  int M, N, K;
+  int c_dtype, act, accumulate;
+  int tiles_m, tiles_n, splits;
+  long kper;   // K elements per split (multiple of the K-step)
+};
+
+__device__ __forceinline__ void store_out(void* C, long off, int c_dtype, float v, int accumulate) {
+  if (c_dtype == MVAE_F32) {
+    float* p = reinterpret_cast<float*>(C) + off;
+    *p = accumulate ? (*p + v) : v;
+  } else {
+    reinterpret_cast<bf16_t*>(C)[off].x = f2bf(v);
+  }
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous
+// range of tiles (neighbouring tiles share an A row panel / B column panel in that XCD's L2).  Bijective for any count.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int split = blockIdx.y;
+  const long kbeg = (long)split * p.kper;
+  const long kend = (kbeg + p.kper < (long)p.K) ? (kbeg + p.kper) : (long)p.K;
+
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+  auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < p.M ? A + (long)gm * p.lda : nullptr; };
+  auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < p.N ? B + (long)gn * p.ldb : nullptr; };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int brow[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) brow[j] = wn * WN + j * 16;
+
+  tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, kbeg, kend, wm * WM, brow, acc, tid);
+
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * WN + j * 16 + lr;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * WM + i * 16 + lq * 4 + r;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splits > 1) {
+          p.partial[((long)split * p.M + row) * p.N + col] = v;
+        } else {
+          if (p.bias) v += p.bias[col];
+          if (p.act == MVAE_ACT_SELU) v = selu_f(v);
+          store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
+  const long n = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / p.N), col = (int)(i - (long)row * p.N);
+    float v = 0.f;
+    for (int s = 0; s < p.splits; ++s) v += p.partial[(long)s * n + i];   // fixed order: deterministic
+    if (p.bias) v += p.bias[col];
+    if (p.act == MVAE_ACT_SELU) v = selu_f(v);
+    store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
+  }
+}
+
+namespace {
+struct Plan { int bm, tiles_m, tiles_n, splits; long kper; };
+
+Plan make_plan(int M, int N, int K, int dtype) {
+  Plan pl;
+  const int ke = (dtype == MVAE_BF16) ? 64 : 32;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  pl.bm = (t128 >= 192) ? 128 : 64;
+  pl.tiles_m = (M + pl.bm - 1) / pl.bm;
+  pl.tiles_n = (N + pl.bm - 1) / pl.bm;
+  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  const long ksteps = (K + ke - 1) / ke;
+  int splits = 1;
+  if (tiles < 128 && ksteps >= 16) {
+    splits = (int)((256 + tiles - 1) / tiles);
+    const long maxs = ksteps / 8;            // at least 8 K-steps per split
+    if (splits > maxs) splits = (int)maxs;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  long per = (ksteps + splits - 1) / splits;
+  splits = (int)((ksteps + per - 1) / per);
+  pl.splits = splits;
+  pl.kper = per * ke;
+  return pl;
+}
+}  // namespace
+
+size_t gemm_nt_workspace_bytes(int M, int N, int K, int dtype) {
+  Plan pl = make_plan(M, N, K, dtype);
+  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+}
+
+int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                   int c_dtype, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (M <= 0 || N <= 0) return MVAE_OK;
+  if (K < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
+  if (dtype != MVAE_F32 && dtype != MVAE_BF16) return MVAE_ERR_INVALID;
+  if (c_dtype != MVAE_F32 && c_dtype != MVAE_BF16) return MVAE_ERR_INVALID;
+  if (accumulate && c_dtype != MVAE_F32) return MVAE_ERR_INVALID;
+  Plan pl = make_plan(M, N, K, dtype);
+  GemmArgs p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.partial = nullptr;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
+  if (pl.splits > 1) {
+    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
+    p.partial = reinterpret_cast<float*>(ws);
+  }
+  dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(256);
+  const size_t lds = (size_t)2 * (pl.bm + pl.bm) * KB;
+  if (dtype == MVAE_BF16) {
+    if (pl.bm == 128) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128, 128>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 64, 64>), grid, block, lds, st, p);
+  } else {
+    if (pl.bm == 128) hipLaunchKernelGGL((gemm_nt_kernel<float, 128, 128>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, 64, 64>), grid, block, lds, st, p);
+  }
+  MVAE_CHECK_HIP(hipGetLastError());
+  if (pl.splits > 1) {
+    long n = (long)M * N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), block, 0, st, p);
+    MVAE_CHECK_HIP(hipGetLastError());
+  }
+  return MVAE_OK;
+}

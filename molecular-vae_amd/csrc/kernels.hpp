@@ -1,0 +1,13 @@
+// Internal launcher declarations (host side).  The extern "C" surface is include/mvae.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "../../include/mvae.h"
+
+size_t gemm_nt_workspace_bytes(int M, int N, int K, int dtype);
+int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                   int c_dtype, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, long lds_, void* dst, long ldd, void* dstT,
+                          long ldt, hipStream_t st);
+int launch_colsum(int M, int N, const float* X, long ldx, float* out, hipStream_t st);
+int launch_selu_bwd(long n, float* dy, const float* y, hipStream_t st);

@@ -1,0 +1,323 @@
+// Recurrent stack on gfx950: layer-wavefront schedule, one launch per wavefront step.
+// Forward cell update  = MFMA tile loop over two K-segments (x_t . W_ih^T, h_{t-1} . W_hh^T) whose output tile
+// holds the 4 gate pre-activations of the same (batch row, hidden unit) in one lane, so the gate
+// non-linearities and the state update run in the epilogue (models.py:128,164 nn.LSTM).
+// Backward cell update = tile loop over (dG_{t+1} . W_hh, dG^{l+1}_t . W_ih^{l+1}) + gate derivative epilogue.
+#include "tile.hpp"
+#include "kernels.hpp"
+
+struct StepTaskF {
+  const void *A0, *A1, *W0, *W1;
+  long lda0, lda1, ldw0, ldw1;
+  int K0, K1;
+  const float* add; long add_ld;
+  const float* bias;
+  const float* c_prev; float* c_out;
+  void* h_out; long ldh;
+  void* hT_out; long ldT; long tcol;
+  void* g_out;
+};
+struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_j; };
+
+template <typename T> struct Vec4;   // 4 consecutive elements as one store
+template <> struct Vec4<float> { typedef float4 type; static __device__ __forceinline__ float4 make(float a, float b, float c, float d) { return make_float4(a, b, c, d); } };
+template <> struct Vec4<bf16_t> { typedef uint2 type; static __device__ __forceinline__ uint2 make(float a, float b, float c, float d) {
+  return make_uint2((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16), (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16)); } };
+
+// store v[0..3] to dstT[col0 .. col0+3] (4 consecutive batch rows of one transposed row)
+template <typename T>
+__device__ __forceinline__ void store_rows4(T* rowbase, long col0, const float (&v)[4], int nvalid) {
+  if (nvalid == 4 && ((col0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(rowbase) & 15) == 0)) {
+    *reinterpret_cast<typename Vec4<T>::type*>(rowbase + col0) = Vec4<T>::make(v[0], v[1], v[2], v[3]);
+  } else {
+    for (int r = 0; r < nvalid; ++r) TT<T>::st(rowbase + col0 + r, v[r]);
+  }
+}
+
+template <typename T, int BM, int BJ>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(BJ == 32, "one 16-wide hidden sub-tile per wave and gate");
+  constexpr int BN = 4 * BJ, WM = BM / 2, MI = WM / 16, NI = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wj = wave & 1;
+  const int per_task = p.tiles_m * p.tiles_j;
+  const int task = blockIdx.x / per_task;
+  const int rem = blockIdx.x - task * per_task;
+  const int tj = rem / p.tiles_m, tm = rem - tj * p.tiles_m;   // consecutive blocks share the weight panel
+  const StepTaskF& q = p.t[task];
+  const int m0 = tm * BM, j0 = tj * BJ, H = p.H, B = p.B;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int g = 0; g < NI; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int brow[NI];
+#pragma unroll
+  for (int g = 0; g < NI; ++g) brow[g] = g * BJ + wj * 16;
+
+  if (q.A0 != nullptr) {
+    const T* A = reinterpret_cast<const T*>(q.A0);
+    const T* W = reinterpret_cast<const T*>(q.W0);
+    const long lda = q.lda0, ldw = q.ldw0;
+    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+    auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
+    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
+  }
+  if (q.A1 != nullptr) {
+    const T* A = reinterpret_cast<const T*>(q.A1);
+    const T* W = reinterpret_cast<const T*>(q.W1);
+    const long lda = q.lda1, ldw = q.ldw1;
+    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+    auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
+    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+  }
+
+  const int j = j0 + wj * 16 + (lane & 15);
+  if (j >= H) return;
+  const int lq = lane >> 4;
+  float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
+  if (q.bias) { bi = q.bias[j]; bf = q.bias[H + j]; bg = q.bias[2 * H + j]; bo = q.bias[3 * H + j]; }
+  T* hout = reinterpret_cast<T*>(q.h_out);
+  T* gout = reinterpret_cast<T*>(q.g_out);
+  T* hT = reinterpret_cast<T*>(q.hT_out);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row0 = m0 + wm * WM + i * 16 + lq * 4;
+    float hv[4] = {0.f, 0.f, 0.f, 0.f};
+    int nvalid = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + r;
+      if (row >= B) continue;
+      nvalid = r + 1;
+      float pi = acc[i][0][r] + bi, pf = acc[i][1][r] + bf, pg = acc[i][2][r] + bg, po = acc[i][3][r] + bo;
+      if (q.add) {
+        const float* a = q.add + (long)row * q.add_ld + j;
+        pi += a[0]; pf += a[H]; pg += a[2 * H]; po += a[3 * H];
+      }
+      const float ig = sigmoid_f(pi), fg = sigmoid_f(pf), gg = tanhf(pg), og = sigmoid_f(po);
+      const float cp = q.c_prev ? q.c_prev[(long)row * H + j] : 0.f;
+      const float c = fg * cp + ig * gg;
+      const float h = og * tanhf(c);
+      q.c_out[(long)row * H + j] = c;
+      TT<T>::st(hout + (long)row * q.ldh + j, h);
+      T* g4 = gout + (long)row * 4 * H + j;
+      TT<T>::st(g4, ig); TT<T>::st(g4 + H, fg); TT<T>::st(g4 + 2 * H, gg); TT<T>::st(g4 + 3 * H, og);
+      hv[r] = h;
+    }
+    if (hT && nvalid > 0) store_rows4<T>(hT + (long)j * q.ldT, q.tcol + row0, hv, nvalid);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+struct StepTaskB {
+  const void *A0, *A1, *W0, *W1;
+  long lda0, lda1, ldw0, ldw1;
+  int K0, K1;
+  const float* dy; long dy_ld;
+  const void* gates; const float* c; const float* c_prev;
+  const float* dc_in; float* dc_out;
+  void* dG; void* dGT; long ldT; long tcol;
+};
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_n; };
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int per_task = p.tiles_m * p.tiles_n;
+  const int task = blockIdx.x / per_task;
+  const int rem = blockIdx.x - task * per_task;
+  const int tn = rem / p.tiles_m, tm = rem - tn * p.tiles_m;
+  const StepTaskB& q = p.t[task];
+  const int m0 = tm * BM, n0 = tn * BN, H = p.H, B = p.B;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int n = 0; n < NI; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int brow[NI];
+#pragma unroll
+  for (int n = 0; n < NI; ++n) brow[n] = wn * WN + n * 16;
+
+  if (q.A0 != nullptr) {
+    const T* A = reinterpret_cast<const T*>(q.A0);
+    const T* W = reinterpret_cast<const T*>(q.W0);
+    const long lda = q.lda0, ldw = q.ldw0;
+    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+    auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
+    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
+  }
+  if (q.A1 != nullptr) {
+    const T* A = reinterpret_cast<const T*>(q.A1);
+    const T* W = reinterpret_cast<const T*>(q.W1);
+    const long lda = q.lda1, ldw = q.ldw1;
+    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+    auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
+    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+  }
+
+  const int lq = lane >> 4;
+  const T* gates = reinterpret_cast<const T*>(q.gates);
+  T* dG = reinterpret_cast<T*>(q.dG);
+  T* dGT = reinterpret_cast<T*>(q.dGT);
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int j = n0 + wn * WN + n * 16 + (lane & 15);
+    if (j >= H) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row0 = m0 + wm * WM + i * 16 + lq * 4;
+      float vi[4] = {0, 0, 0, 0}, vf[4] = {0, 0, 0, 0}, vg[4] = {0, 0, 0, 0}, vo[4] = {0, 0, 0, 0};
+      int nvalid = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + r;
+        if (row >= B) continue;
+        nvalid = r + 1;
+        float dh = acc[i][n][r];
+        if (q.dy) dh += q.dy[(long)row * q.dy_ld + j];
+        const T* g4 = gates + (long)row * 4 * H + j;
+        const float ig = TT<T>::ld(g4), fg = TT<T>::ld(g4 + H), gg = TT<T>::ld(g4 + 2 * H), og = TT<T>::ld(g4 + 3 * H);
+        const long o = (long)row * H + j;
+        const float c = q.c[o];
+        const float cp = q.c_prev ? q.c_prev[o] : 0.f;
+        const float tc = tanhf(c);
+        const float d_o = dh * tc;
+        const float dc = dh * og * (1.f - tc * tc) + (q.dc_in ? q.dc_in[o] : 0.f);
+        q.dc_out[o] = dc * fg;
+        vi[r] = dc * gg * ig * (1.f - ig);
+        vf[r] = dc * cp * fg * (1.f - fg);
+        vg[r] = dc * ig * (1.f - gg * gg);
+        vo[r] = d_o * og * (1.f - og);
+        T* d4 = dG + (long)row * 4 * H + j;
+        TT<T>::st(d4, vi[r]); TT<T>::st(d4 + H, vf[r]); TT<T>::st(d4 + 2 * H, vg[r]); TT<T>::st(d4 + 3 * H, vo[r]);
+      }
+      if (dGT && nvalid > 0) {
+        store_rows4<T>(dGT + (long)j * q.ldT, q.tcol + row0, vi, nvalid);
+        store_rows4<T>(dGT + ((long)H + j) * q.ldT, q.tcol + row0, vf, nvalid);
+        store_rows4<T>(dGT + ((long)2 * H + j) * q.ldT, q.tcol + row0, vg, nvalid);
+        store_rows4<T>(dGT + ((long)3 * H + j) * q.ldT, q.tcol + row0, vo, nvalid);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host drivers
+static inline const char* adv(const void* p, long elems, int dtype) {
+  return reinterpret_cast<const char*>(p) + elems * (dtype == MVAE_BF16 ? 2 : 4);
+}
+
+int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
+  if (!d) return MVAE_ERR_INVALID;
+  if (d->cell != MVAE_CELL_LSTM) return MVAE_ERR_UNSUPPORTED;
+  if (d->layers < 1 || d->layers > MVAE_MAX_LAYERS || d->T < 1 || d->B < 1 || d->H < 1) return MVAE_ERR_INVALID;
+  if (d->dtype != MVAE_F32 && d->dtype != MVAE_BF16) return MVAE_ERR_INVALID;
+  const int NL = d->layers, T = d->T, B = d->B, H = d->H, dt = d->dtype;
+  const int epc = (dt == MVAE_BF16) ? 8 : 4;
+  for (int l = 0; l < NL; ++l) {
+    if (!d->w_hh[l] || !d->hs[l] || !d->cs[l] || !d->gates[l]) return MVAE_ERR_INVALID;
+    if (l > 0 && !d->w_ih[l]) return MVAE_ERR_INVALID;
+    if (d->ldw_hh[l] % epc) return MVAE_ERR_INVALID;
+    if (l > 0 && d->ldw_ih[l] % epc) return MVAE_ERR_INVALID;
+  }
+  if (d->x0 && (!d->w_ih[0] || d->in0 < 1)) return MVAE_ERR_INVALID;
+  if (!d->x0 && !d->add0) return MVAE_ERR_INVALID;
+  if (d->ldh % epc) return MVAE_ERR_INVALID;
+  const int BM = (B > 64 && ((B + 127) / 128) * ((H + 31) / 32) * NL >= 256) ? 128 : 64;
+  StepArgsF a;
+  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + 31) / 32;
+  for (int dd = 0; dd < T + NL - 1; ++dd) {
+    int n = 0;
+    for (int l = 0; l < NL; ++l) {
+      const int t = dd - l;
+      if (t < 0 || t >= T) continue;
+      StepTaskF& q = a.t[n++];
+      if (l == 0) {
+        q.A0 = d->x0 ? adv(d->x0, (long)t * B * d->x0_ld, dt) : nullptr;
+        q.lda0 = d->x0_ld; q.K0 = d->in0; q.W0 = d->w_ih[0]; q.ldw0 = d->ldw_ih[0];
+        q.add = d->add0 ? d->add0 + (long)t * d->add0_tstride : nullptr;
+        q.add_ld = 4L * H;
+      } else {
+        q.A0 = adv(d->hs[l - 1], (long)t * B * d->ldh, dt);
+        q.lda0 = d->ldh; q.K0 = H; q.W0 = d->w_ih[l]; q.ldw0 = d->ldw_ih[l];
+        q.add = nullptr; q.add_ld = 0;
+      }
+      q.A1 = (t > 0) ? adv(d->hs[l], (long)(t - 1) * B * d->ldh, dt) : d->h0[l];
+      q.lda1 = (t > 0) ? d->ldh : d->ldh0;
+      q.K1 = H; q.W1 = d->w_hh[l]; q.ldw1 = d->ldw_hh[l];
+      q.bias = d->bias[l];
+      q.c_prev = (t > 0) ? d->cs[l] + (long)(t - 1) * B * H : nullptr;
+      q.c_out = d->cs[l] + (long)t * B * H;
+      q.h_out = const_cast<char*>(adv(d->hs[l], (long)t * B * d->ldh, dt)); q.ldh = d->ldh;
+      q.hT_out = d->hsT[l]; q.ldT = d->ldT; q.tcol = (long)t * B;
+      q.g_out = const_cast<char*>(adv(d->gates[l], (long)t * B * 4 * H, dt));
+    }
+    a.ntask = n;
+    dim3 grid(n * a.tiles_m * a.tiles_j), block(256);
+    const size_t lds = (size_t)2 * (BM + 128) * KB;
+    if (dt == MVAE_BF16) {
+      if (BM == 128) hipLaunchKernelGGL((lstm_step_fwd_kernel<bf16_t, 128, 32>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((lstm_step_fwd_kernel<bf16_t, 64, 32>), grid, block, lds, st, a);
+    } else {
+      if (BM == 128) hipLaunchKernelGGL((lstm_step_fwd_kernel<float, 128, 32>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((lstm_step_fwd_kernel<float, 64, 32>), grid, block, lds, st, a);
+    }
+  }
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
+  if (!d) return MVAE_ERR_INVALID;
+  if (d->cell != MVAE_CELL_LSTM) return MVAE_ERR_UNSUPPORTED;
+  if (d->layers < 1 || d->layers > MVAE_MAX_LAYERS || d->T < 1 || d->B < 1 || d->H < 1) return MVAE_ERR_INVALID;
+  if (d->dtype != MVAE_F32 && d->dtype != MVAE_BF16) return MVAE_ERR_INVALID;
+  const int NL = d->layers, T = d->T, B = d->B, H = d->H, dt = d->dtype;
+  const int epc = (dt == MVAE_BF16) ? 8 : 4;
+  if (!d->dy) return MVAE_ERR_INVALID;
+  for (int l = 0; l < NL; ++l) {
+    if (!d->w_hhT[l] || !d->cs[l] || !d->gates[l] || !d->dG[l] || !d->dstate[l]) return MVAE_ERR_INVALID;
+    if (l > 0 && !d->w_ihT[l]) return MVAE_ERR_INVALID;
+    if (d->ldw_hhT[l] % epc || (l > 0 && d->ldw_ihT[l] % epc)) return MVAE_ERR_INVALID;
+  }
+  if ((4L * H) % epc) return MVAE_ERR_INVALID;
+  const int BM = (B > 64 && ((B + 127) / 128) * ((H + 63) / 64) * NL >= 200) ? 128 : 64;
+  StepArgsB a;
+  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + 63) / 64;
+  for (int e = T + NL - 2; e >= 0; --e) {
+    int n = 0;
+    for (int l = 0; l < NL; ++l) {
+      const int t = e - l;
+      if (t < 0 || t >= T) continue;
+      StepTaskB& q = a.t[n++];
+      q.A0 = (t < T - 1) ? adv(d->dG[l], (long)(t + 1) * B * 4 * H, dt) : nullptr;
+      q.lda0 = 4L * H; q.K0 = 4 * H; q.W0 = d->w_hhT[l]; q.ldw0 = d->ldw_hhT[l];
+      q.A1 = (l < NL - 1) ? adv(d->dG[l + 1], (long)t * B * 4 * H, dt) : nullptr;
+      q.lda1 = 4L * H; q.K1 = 4 * H; q.W1 = (l < NL - 1) ? d->w_ihT[l + 1] : nullptr; q.ldw1 = (l < NL - 1) ? d->ldw_ihT[l + 1] : 0;
+      q.dy = (l == NL - 1) ? d->dy + (long)t * B * d->dy_ld : nullptr; q.dy_ld = d->dy_ld;
+      q.gates = adv(d->gates[l], (long)t * B * 4 * H, dt);
+      q.c = d->cs[l] + (long)t * B * H;
+      q.c_prev = (t > 0) ? d->cs[l] + (long)(t - 1) * B * H : nullptr;
+      q.dc_in = (t < T - 1) ? d->dstate[l] + (long)((t + 1) & 1) * B * H : nullptr;
+      q.dc_out = d->dstate[l] + (long)(t & 1) * B * H;
+      q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * 4 * H, dt));
+      q.dGT = d->dGT[l]; q.ldT = d->ldT; q.tcol = (long)t * B;
+    }
+    a.ntask = n;
+    dim3 grid(n * a.tiles_m * a.tiles_n), block(256);
+    const size_t lds = (size_t)2 * (BM + 64) * KB;
+    if (dt == MVAE_BF16) {
+      if (BM == 128) hipLaunchKernelGGL((lstm_step_bwd_kernel<bf16_t, 128, 64>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((lstm_step_bwd_kernel<bf16_t, 64, 64>), grid, block, lds, st, a);
+    } else {
+      if (BM == 128) hipLaunchKernelGGL((lstm_step_bwd_kernel<float, 128, 64>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((lstm_step_bwd_kernel<float, 64, 64>), grid, block, lds, st, a);
+    }
+  }
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}

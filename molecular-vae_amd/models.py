@@ -1,0 +1,596 @@
+"""Host-side mirror of the reference's ``models.py`` module surface (models.py:97-165), MI355X-native underneath.
+
+Same class names, constructor arguments, attribute names, ``forward`` signatures and ``state_dict`` keys as the
+reference, so ``train.py:77-104`` runs against these modules unchanged.  The modules own
+ordinary fp32 ``nn.Parameter``s; ``forward`` hands raw device pointers to the HIP kernels behind ``include/mvae.h``
+through ``torch.autograd.Function``s.  There is no torch.nn compute and no CPU fallback on this path.
+
+Differences that are deliberate and documented:
+  * ``MolEncoder.forward(x, eps=None)`` / ``Lambda``: the reparameterisation noise may be injected (parity tests);
+    when omitted it is drawn exactly as the reference does (``scale * torch.randn`` on the CPU default generator,
+    models.py:92) into pinned memory and copied asynchronously.
+  * ``dtype=torch.bfloat16`` (default) stores the decoder LSTM's weights/activations in bf16 with fp32 accumulation,
+    cell state and master weights (BASELINE.json configs[1]); ``dtype=torch.float32`` is the exact-f32 MFMA path.
+    The encoder always runs in f32 (mu / logvar parity).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------------------------- parameter holders
+class _NoCompute(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__} only holds parameters; the arithmetic runs in the fused HIP path "
+                           "of the enclosing MolEncoder / MolDecoder")
+
+
+class LinearWeights(_NoCompute):
+    """weight [out,in], bias [out]; initialised like nn.Linear (same RNG consumption as the reference's modules)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class Conv1dWeights(_NoCompute):
+    """weight [out,in,k], bias [out]; initialised like nn.Conv1d."""
+
+    def __init__(self, in_channels, out_channels, kernel_size):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_channels * kernel_size)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class EmbeddingWeights(_NoCompute):
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        nn.init.normal_(self.weight)
+
+
+class RNNWeights(_NoCompute):
+    """weight_ih_l{k}, weight_hh_l{k}, bias_ih_l{k}, bias_hh_l{k} with torch.nn.LSTM/GRU names, shapes, order, init."""
+
+    def __init__(self, mode, input_size, hidden_size, num_layers):
+        super().__init__()
+        self.mode, self.input_size, self.hidden_size, self.num_layers = mode, input_size, hidden_size, num_layers
+        g = {"LSTM": 4, "GRU": 3}[mode] * hidden_size
+        for l in range(num_layers):
+            inp = input_size if l == 0 else hidden_size
+            self.register_parameter(f"weight_ih_l{l}", nn.Parameter(torch.empty(g, inp)))
+            self.register_parameter(f"weight_hh_l{l}", nn.Parameter(torch.empty(g, hidden_size)))
+            self.register_parameter(f"bias_ih_l{l}", nn.Parameter(torch.empty(g)))
+            self.register_parameter(f"bias_hh_l{l}", nn.Parameter(torch.empty(g)))
+        stdv = 1.0 / math.sqrt(hidden_size)
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+
+class SELU(nn.Module):
+    """Marker for scale*ELU_alpha (models.py:58-68); fused into the producing GEMM's epilogue."""
+
+    def __init__(self, alpha=1.6732632423543772848170429916717, scale=1.0507009873554804934193349852946, inplace=False):
+        super().__init__()
+        self.alpha, self.scale = alpha, scale
+
+
+class Softmax(nn.Module):
+    """Marker for the class-axis softmax of models.py:157-158; fused into the output head."""
+
+
+def ConvSELU(i, o, kernel_size=3, padding=0, p=0.):
+    """models.py:71-77.  padding / dropout are not on the training path (always 0 there)."""
+    if padding != 0 or p > 0.:
+        raise NotImplementedError("ConvSELU: only padding=0, p=0 (the configuration models.py:118-120 uses)")
+    return nn.Sequential(Conv1dWeights(i, o, kernel_size), SELU(inplace=True))
+
+
+class Flatten(nn.Module):
+    def forward(self, x):
+        return x.reshape(x.size(0), -1)
+
+
+class Repeat(nn.Module):
+    """models.py:13-26.  The fused decoder never materialises the repeat (time-invariant layer-0 input)."""
+
+    def __init__(self, rep):
+        super().__init__()
+        self.rep = rep
+
+    def forward(self, x):
+        return x.unsqueeze(1).expand(x.size(0), self.rep, *x.shape[1:]).contiguous()
+
+
+class TimeDistributed(nn.Module):
+    """models.py:29-55 container (key ``decoded_mean.module.0.*``)."""
+
+    def __init__(self, module, batch_first=True):
+        super().__init__()
+        self.module = module
+        self.batch_first = batch_first
+
+
+# ----------------------------------------------------------------------------------------------- workspace / packing
+class _Workspace:
+    """Named device buffers, allocated once per shape and reused every step (zero-initialised: pad regions stay 0)."""
+
+    def __init__(self):
+        self.bufs = {}
+        self.generation = 0
+
+    def get(self, name, shape, dtype, device):
+        key = (name, tuple(shape), dtype, device)
+        b = self.bufs.get(key)
+        if b is None:
+            b = torch.zeros(shape, dtype=dtype, device=device)
+            self.bufs[key] = b
+        return b
+
+
+def _require_cuda(dev, what):
+    if dev.type != "cuda":
+        raise L.MvaeError(f"{what} runs on the MI355X only (no CPU fallback); move the module and inputs to cuda")
+
+
+def _params_key(params):
+    return (L.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params)
+
+
+class Lambda(nn.Module):
+    """models.py:80-94: z_mean / z_log_var heads + reparameterisation; caches ``.mu`` / ``.log_v``."""
+
+    def __init__(self, i=435, o=292, scale=1E-2):
+        super().__init__()
+        self.scale = scale
+        self.z_mean = LinearWeights(i, o)
+        self.z_log_var = LinearWeights(i, o)
+
+    def draw_eps(self, B, o, device):
+        # models.py:92: scale * randn(*size) on the CPU default generator, then type_as(log_v)
+        e = torch.randn(B, o, pin_memory=device.type == "cuda")
+        e.mul_(self.scale)                      # in place: stays in pinned memory, so the copy below is asynchronous
+        return e.to(device, non_blocking=True)
+
+    def forward(self, x, eps=None):
+        from .functional import lambda_forward
+        z, self.mu, self.log_v = lambda_forward(self, x, eps)
+        return z, self.mu, self.log_v
+
+
+# ----------------------------------------------------------------------------------------------- encoder
+class MolEncoder(nn.Module):
+    """models.py:109-135: Embedding -> LSTM(30->72, 3 layers) -> 3 x (Conv1d k=18 + SELU) -> Linear+SELU -> Lambda."""
+
+    def __init__(self, i=120, o=292, c=35, word_embedding_size=30, h_size=72, num_lstm=3):
+        super().__init__()
+        self.i = i
+        self.embedding = EmbeddingWeights(c, word_embedding_size)
+        self.gru = RNNWeights("LSTM", word_embedding_size, h_size, num_lstm)      # attribute is named gru, is an LSTM (models.py:117)
+        self.conv_1 = ConvSELU(i, 120, kernel_size=18)
+        self.conv_2 = ConvSELU(120, 64, kernel_size=18)
+        self.conv_3 = ConvSELU(64, 64, kernel_size=18)
+        self.dense_1 = nn.Sequential(LinearWeights((h_size - (18 * 3) + 3) * 64, 512), SELU(inplace=True))
+        self.lmbd = Lambda(512, o)
+        self._ws = _Workspace()
+        self._pack_key = None
+        self._packed = {}
+
+    def forward(self, x, eps=None):
+        B = x.shape[0]
+        o = self.lmbd.z_mean.out_features
+        if eps is None:
+            eps = self.lmbd.draw_eps(B, o, x.device)
+        params = list(self.parameters())
+        z, mu, logv = _EncoderFn.apply(self, x, eps, *params)
+        self.lmbd.mu, self.lmbd.log_v = mu, logv
+        return z, mu, logv
+
+    # -- packed weight shadows (refreshed when any parameter changed)
+    def _pack(self, dev):
+        params = list(self.parameters())
+        key = _params_key(params)
+        if key == self._pack_key:
+            return self._packed
+        g, ws = self.gru, self._ws
+        H, NL, E, Cv = g.hidden_size, g.num_layers, g.input_size, self.embedding.num_embeddings
+        P = {}
+        with torch.no_grad():
+            Ep = _pad(E, 4)
+            P["E_p"] = ws.get("E_p", (Cv, Ep), torch.float32, dev)
+            ops.cast_transpose(self.embedding.weight, Cv, E, dst=P["E_p"])
+            P["ET"] = ws.get("ET", (E, _pad(Cv, 4)), torch.float32, dev)
+            ops.cast_transpose(self.embedding.weight, Cv, E, dstT=P["ET"])
+            P["Wih0_p"] = ws.get("Wih0_p", (4 * H, Ep), torch.float32, dev)
+            P["Wih0T"] = ws.get("Wih0T", (E, 4 * H), torch.float32, dev)
+            ops.cast_transpose(g.weight_ih_l0, 4 * H, E, dst=P["Wih0_p"], dstT=P["Wih0T"])
+            P["bias"] = []
+            P["WihT"], P["WhhT"] = [None], []
+            for l in range(NL):
+                b = ws.get(f"bias{l}", (4 * H,), torch.float32, dev)
+                torch.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), out=b)
+                P["bias"].append(b)
+                t = ws.get(f"WhhT{l}", (H, 4 * H), torch.float32, dev)
+                ops.cast_transpose(getattr(g, f"weight_hh_l{l}"), 4 * H, H, dstT=t)
+                P["WhhT"].append(t)
+                if l > 0:
+                    t = ws.get(f"WihT{l}", (H, 4 * H), torch.float32, dev)
+                    ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), 4 * H, H, dstT=t)
+                    P["WihT"].append(t)
+            for n, conv in (("c1", self.conv_1[0]), ("c2", self.conv_2[0]), ("c3", self.conv_3[0])):
+                K = conv.in_channels * conv.kernel_size
+                t = ws.get(n + "_wT", (K, conv.out_channels), torch.float32, dev)
+                ops.cast_transpose(conv.weight.view(conv.out_channels, K), conv.out_channels, K, dstT=t)
+                P[n + "_wT"] = t
+            d1 = self.dense_1[0]
+            P["W1T"] = ws.get("W1T", (d1.in_features, d1.out_features), torch.float32, dev)
+            ops.cast_transpose(d1.weight, d1.out_features, d1.in_features, dstT=P["W1T"])
+            o = self.lmbd.z_mean.out_features
+            P["Wml"] = ws.get("Wml", (2 * o, 512), torch.float32, dev)
+            P["Wml"][:o].copy_(self.lmbd.z_mean.weight); P["Wml"][o:].copy_(self.lmbd.z_log_var.weight)
+            P["bml"] = ws.get("bml", (2 * o,), torch.float32, dev)
+            P["bml"][:o].copy_(self.lmbd.z_mean.bias); P["bml"][o:].copy_(self.lmbd.z_log_var.bias)
+            P["WmlT"] = ws.get("WmlT", (512, _pad(2 * o, 4)), torch.float32, dev)
+            ops.cast_transpose(P["Wml"], 2 * o, 512, dstT=P["WmlT"])
+        self._pack_key, self._packed = key, P
+        return P
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, idx, eps, *params):
+        dev = idx.device
+        _require_cuda(dev, "MolEncoder")
+        idx = idx.contiguous()
+        eps = eps.contiguous().float()
+        B, Lq = idx.shape
+        if Lq != mod.i:
+            raise ValueError(f"sequence length {Lq} != encoder i={mod.i}")
+        g = mod.gru
+        H, NL, Cv = g.hidden_size, g.num_layers, mod.embedding.num_embeddings
+        o = mod.lmbd.z_mean.out_features
+        P = mod._pack(dev)
+        ws = mod._ws
+        ws.generation += 1
+        f32 = torch.float32
+        G4 = 4 * H
+        TB = Lq * B
+        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
+        # K1: embedding folded into the layer-0 input projection: table = E . W_ih0^T + (b_ih0 + b_hh0)
+        tbl = ws.get("tbl", (Cv, G4), f32, dev)
+        Ep = P["E_p"].shape[1]
+        ops.gemm_nt(P["E_p"], P["Wih0_p"], tbl, Cv, G4, Ep, bias=P["bias"][0])
+        gx0 = ws.get("gx0", (Lq, B, G4), f32, dev)
+        ops.gather_rows_tb(idx, tbl, gx0, B, Lq, Cv, G4)
+        # K2: 3-layer LSTM, f32 MFMA
+        hs = [ws.get(f"hs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
+        hsT = [ws.get(f"hsT{l}", (H, ldT), f32, dev) for l in range(NL)]
+        cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
+        gates = [ws.get(f"gates{l}", (Lq, B, G4), f32, dev) for l in range(NL)]
+        w_ih = [None] + [getattr(g, f"weight_ih_l{l}") for l in range(1, NL)]
+        w_hh = [getattr(g, f"weight_hh_l{l}") for l in range(NL)]
+        ops.rnn_fwd(L.CELL_LSTM, f32, Lq, B, H, gx0, B * G4, w_ih, [H] * NL, w_hh, [H] * NL, [None] + P["bias"][1:],
+                    hs, H, hsT, ldT, cs, gates)
+        # K3: conv stack over the hidden axis, sequence position = channel (models.py:129-131)
+        c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
+        k = c1.kernel_size
+        W1, W2, W3 = H - k + 1, H - 2 * k + 2, H - 3 * k + 3
+        col1 = ws.get("col1", (B * W1, Lq * k), f32, dev); y1 = ws.get("y1", (B * W1, c1.out_channels), f32, dev)
+        ops.conv1d_selu_fwd(hs[-1], (H, B * H, 1), B, Lq, H, c1.out_channels, k, c1.weight, c1.bias, col1, y1)
+        col2 = ws.get("col2", (B * W2, c2.in_channels * k), f32, dev); y2 = ws.get("y2", (B * W2, c2.out_channels), f32, dev)
+        ops.conv1d_selu_fwd(y1, (W1 * c1.out_channels, 1, c1.out_channels), B, c2.in_channels, W1, c2.out_channels, k,
+                            c2.weight, c2.bias, col2, y2)
+        col3 = ws.get("col3", (B * W3, c3.in_channels * k), f32, dev); y3 = ws.get("y3", (B * W3, c3.out_channels), f32, dev)
+        ops.conv1d_selu_fwd(y2, (W2 * c2.out_channels, 1, c2.out_channels), B, c3.in_channels, W2, c3.out_channels, k,
+                            c3.weight, c3.bias, col3, y3)
+        # Flatten is channel-major (models.py:6-10): flat[b, co*W3 + w] = y3[(b*W3 + w), co]
+        C3 = c3.out_channels
+        flat = ws.get("flat", (B, C3 * W3), f32, dev)
+        ops.permute021(y3, flat, B, W3, C3)
+        # K4: dense + SELU
+        d1 = mod.dense_1[0]
+        d = ws.get("d", (B, d1.out_features), f32, dev)
+        ops.gemm_nt(flat, d1.weight, d, B, d1.out_features, d1.in_features, bias=d1.bias, act=L.ACT_SELU)
+        # K5: stacked heads + reparameterisation
+        mulv = ws.get("mulv", (B, 2 * o), f32, dev)
+        ops.gemm_nt(d, P["Wml"], mulv, B, 2 * o, 512, bias=P["bml"])
+        z = torch.empty(B, o, dtype=f32, device=dev); mu = torch.empty_like(z); logv = torch.empty_like(z)
+        ops.lambda_fwd(mulv, eps, z, mu, logv, B, o)
+        ctx.mod, ctx.gen, ctx.idx, ctx.eps = mod, ws.generation, idx, eps
+        return z, mu, logv
+
+    @staticmethod
+    def backward(ctx, dz, dmu, dlogv):
+        mod, idx, eps = ctx.mod, ctx.idx, ctx.eps
+        ws = mod._ws
+        if ws.generation != ctx.gen:
+            raise L.MvaeError("MolEncoder workspace was overwritten by a later forward; run backward before the next forward")
+        dev = idx.device
+        f32 = torch.float32
+        B, Lq = idx.shape
+        g = mod.gru
+        H, NL, Cv, E = g.hidden_size, g.num_layers, mod.embedding.num_embeddings, g.input_size
+        o = mod.lmbd.z_mean.out_features
+        G4, TB = 4 * H, Lq * B
+        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
+        Bp = _pad(B, 4)
+        P = mod._packed
+        params = list(mod.parameters())
+        names = [n for n, _ in mod.named_parameters()]
+        total = sum(p.numel() for p in params)
+        gflat = torch.zeros(total, dtype=f32, device=dev)
+        grads, off = {}, 0
+        for n, p in zip(names, params):
+            grads[n] = gflat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        dz = dz.contiguous() if dz is not None else None
+        dmu = dmu.contiguous() if dmu is not None else None
+        dlogv = dlogv.contiguous() if dlogv is not None else None
+        W = lambda name, shape: ws.get(name, shape, f32, dev)
+        # K5 backward
+        mulv, d = W("mulv", (B, 2 * o)), W("d", (B, 512))
+        dmulv = W("dmulv", (B, 2 * o))
+        ops.lambda_bwd(mulv, eps, dz, dmu, dlogv, dmulv, B, o)
+        dmulvT, dT = W("dmulvT", (2 * o, Bp)), W("dT", (512, Bp))
+        ops.cast_transpose(dmulv, B, 2 * o, dstT=dmulvT); ops.cast_transpose(d, B, 512, dstT=dT)
+        dWml = W("dWml", (2 * o, 512)); dbml = W("dbml", (2 * o,))
+        ops.gemm_nt(dmulvT, dT, dWml, 2 * o, 512, Bp)
+        ops.colsum(dmulv, B, 2 * o, dbml)
+        grads["lmbd.z_mean.weight"].copy_(dWml[:o]); grads["lmbd.z_log_var.weight"].copy_(dWml[o:])
+        grads["lmbd.z_mean.bias"].copy_(dbml[:o]); grads["lmbd.z_log_var.bias"].copy_(dbml[o:])
+        dd = W("dd", (B, 512))
+        ops.gemm_nt(dmulv, P["WmlT"], dd, B, 512, 2 * o, ldb=P["WmlT"].stride(0))
+        ops.selu_bwd(dd, d)
+        # K4 backward
+        d1 = mod.dense_1[0]
+        F = d1.in_features
+        flat = W("flat", (B, F))
+        ddT, flatT = W("ddT", (512, Bp)), W("flatT", (F, Bp))
+        ops.cast_transpose(dd, B, 512, dstT=ddT); ops.cast_transpose(flat, B, F, dstT=flatT)
+        ops.gemm_nt(ddT, flatT, grads["dense_1.0.weight"], 512, F, Bp)
+        ops.colsum(dd, B, 512, grads["dense_1.0.bias"])
+        dflat = W("dflat", (B, F))
+        ops.gemm_nt(dd, P["W1T"], dflat, B, F, 512)
+        # K3 backward
+        c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
+        k = c1.kernel_size
+        W1, W2, W3 = H - k + 1, H - 2 * k + 2, H - 3 * k + 3
+        C3 = c3.out_channels
+        dy3 = W("dy3", (B * W3, C3))
+        ops.permute021(dflat, dy3, B, C3, W3)
+        y1, y2, y3 = W("y1", (B * W1, c1.out_channels)), W("y2", (B * W2, c2.out_channels)), W("y3", (B * W3, C3))
+        col1, col2, col3 = W("col1", (B * W1, Lq * k)), W("col2", (B * W2, c2.in_channels * k)), W("col3", (B * W3, c3.in_channels * k))
+        dy2 = W("dy2", (B * W2, c2.out_channels)); dy1 = W("dy1", (B * W1, c1.out_channels)); dhs = W("dhs", (Lq, B, H))
+        ops.conv1d_selu_bwd(B, c3.in_channels, W2, C3, k, dy3, y3, col3, P["c3_wT"], C3, grads["conv_3.0.weight"],
+                            grads["conv_3.0.bias"], dy2, (W2 * c2.out_channels, 1, c2.out_channels))
+        ops.conv1d_selu_bwd(B, c2.in_channels, W1, c2.out_channels, k, dy2, y2, col2, P["c2_wT"], c2.out_channels,
+                            grads["conv_2.0.weight"], grads["conv_2.0.bias"], dy1, (W1 * c1.out_channels, 1, c1.out_channels))
+        ops.conv1d_selu_bwd(B, Lq, H, c1.out_channels, k, dy1, y1, col1, P["c1_wT"], c1.out_channels,
+                            grads["conv_1.0.weight"], grads["conv_1.0.bias"], dhs, (H, B * H, 1))
+        # K2 backward (reverse wavefront) + weight gradients
+        hs = [W(f"hs{l}", (Lq, B, H)) for l in range(NL)]
+        hsT = [W(f"hsT{l}", (H, ldT)) for l in range(NL)]
+        cs = [W(f"cs{l}", (Lq, B, H)) for l in range(NL)]
+        gates = [W(f"gates{l}", (Lq, B, G4)) for l in range(NL)]
+        dG = [W(f"dG{l}", (Lq, B, G4)) for l in range(NL)]
+        dGT = [W(f"dGT{l}", (G4, ldT)) for l in range(NL)]
+        dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
+        ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, H, cs, gates,
+                    dG, dGT, ldT, dstate)
+        for l in range(NL):
+            if Lq > 1:
+                ops.gemm_nt(dGT[l][:, B:], hsT[l], grads[f"gru.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
+            if l > 0:
+                ops.gemm_nt(dGT[l], hsT[l - 1], grads[f"gru.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
+            ops.rowsum(dGT[l], G4, TB, grads[f"gru.bias_ih_l{l}"])
+            grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
+        # K1 backward: table gradient, then embedding / W_ih0
+        dtbl = W("dtbl", (Cv, G4))
+        ops.scatter_rows_tb(idx, dG[0], dtbl, B, Lq, Cv, G4)
+        ops.gemm_nt(dtbl, P["Wih0T"], grads["embedding.weight"], Cv, E, G4)
+        Cp = _pad(Cv, 4)
+        dtblT = W("dtblT", (G4, Cp))
+        ops.cast_transpose(dtbl, Cv, G4, dstT=dtblT)
+        ops.gemm_nt(dtblT, P["ET"], grads["gru.weight_ih_l0"], G4, E, Cp)
+        return (None, None, None) + tuple(grads[n] for n in names)
+
+
+# ----------------------------------------------------------------------------------------------- decoder
+class MolDecoder(nn.Module):
+    """models.py:148-165: Linear+SELU -> repeat L -> LSTM(292->1024, 4 layers) -> Linear(1024,C) -> softmax over C."""
+
+    def __init__(self, i=292, o=120, c=35, num_gru=4, h_size=1024, dtype=torch.bfloat16):
+        super().__init__()
+        self.latent_input = nn.Sequential(LinearWeights(i, i), SELU(inplace=True))
+        self.repeat_vector = Repeat(o)
+        self.gru = RNNWeights("LSTM", i, h_size, num_gru)                           # models.py:156: named gru, is an LSTM
+        self.decoded_mean = TimeDistributed(nn.Sequential(LinearWeights(h_size, c), Softmax()))
+        self.compute_dtype = dtype
+        self._ws = _Workspace()
+        self._pack_key = None
+        self._packed = {}
+
+    def forward(self, x):
+        return _DecoderFn.apply(self, x, *list(self.parameters()))
+
+    def _pack(self, dev):
+        params = list(self.parameters())
+        key = _params_key(params) + (self.compute_dtype,)
+        if key == self._pack_key:
+            return self._packed
+        g, ws, dt = self.gru, self._ws, self.compute_dtype
+        H, NL, o = g.hidden_size, g.num_layers, g.input_size
+        G4 = 4 * H
+        f32 = torch.float32
+        P = {"Wih": [None], "WihT": [None], "Whh": [], "WhhT": [], "bias": []}
+        with torch.no_grad():
+            li = self.latent_input[0]
+            P["WliT"] = ws.get("WliT", (o, _pad(o, 4)), f32, dev)
+            ops.cast_transpose(li.weight, o, o, dstT=P["WliT"])
+            P["Wih0T"] = ws.get("Wih0T", (o, G4), f32, dev)
+            ops.cast_transpose(g.weight_ih_l0, G4, o, dstT=P["Wih0T"])
+            for l in range(NL):
+                b = ws.get(f"bias{l}", (G4,), f32, dev)
+                torch.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), out=b)
+                P["bias"].append(b)
+                w = ws.get(f"Whh{l}", (G4, H), dt, dev); wT = ws.get(f"WhhT{l}", (H, G4), dt, dev)
+                ops.cast_transpose(getattr(g, f"weight_hh_l{l}"), G4, H, dst=w, dstT=wT)
+                P["Whh"].append(w); P["WhhT"].append(wT)
+                if l > 0:
+                    w = ws.get(f"Wih{l}", (G4, H), dt, dev); wT = ws.get(f"WihT{l}", (H, G4), dt, dev)
+                    ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), G4, H, dst=w, dstT=wT)
+                    P["Wih"].append(w); P["WihT"].append(wT)
+            om = self.decoded_mean.module[0]
+            Cv = om.out_features
+            Cp = _pad(Cv, 8)
+            P["Wout"] = ws.get("Wout", (Cv, H), dt, dev)
+            P["WoutT"] = ws.get("WoutT", (H, Cp), dt, dev)
+            ops.cast_transpose(om.weight, Cv, H, dst=P["Wout"], dstT=P["WoutT"])
+        self._pack_key, self._packed = key, P
+        return P
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, z, *params):
+        dev = z.device
+        _require_cuda(dev, "MolDecoder")
+        z = z.contiguous().float()
+        g, dt = mod.gru, mod.compute_dtype
+        H, NL, o = g.hidden_size, g.num_layers, g.input_size
+        B = z.shape[0]
+        Lq = mod.repeat_vector.rep
+        om = mod.decoded_mean.module[0]
+        Cv = om.out_features
+        G4, TB = 4 * H, Lq * B
+        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
+        P = mod._pack(dev)
+        ws = mod._ws
+        ws.generation += 1
+        f32 = torch.float32
+        li_mod = mod.latent_input[0]
+        # K6: latent projection + SELU; layer-0 input is time-invariant -> its gate pre-activation is computed ONCE
+        li = ws.get("li", (B, o), f32, dev)
+        ops.gemm_nt(z, li_mod.weight, li, B, o, o, bias=li_mod.bias, act=L.ACT_SELU)
+        gx0 = ws.get("gx0", (B, G4), f32, dev)
+        ops.gemm_nt(li, g.weight_ih_l0, gx0, B, G4, o, bias=P["bias"][0])
+        # K7: 4-layer LSTM wavefront
+        hs = [ws.get(f"hs{l}", (Lq, B, H), dt, dev) for l in range(NL)]
+        hsT = [ws.get(f"hsT{l}", (H, ldT), dt, dev) for l in range(NL)]
+        cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
+        gates = [ws.get(f"gates{l}", (Lq, B, G4), dt, dev) for l in range(NL)]
+        ops.rnn_fwd(L.CELL_LSTM, dt, Lq, B, H, gx0, 0, P["Wih"], [H] * NL, P["Whh"], [H] * NL, [None] + P["bias"][1:],
+                    hs, H, hsT, ldT, cs, gates)
+        # K8: output head + softmax over the class axis
+        logits = ws.get("logits", (TB, Cv), f32, dev)
+        ops.gemm_nt(hs[-1].view(TB, H), P["Wout"], logits, TB, Cv, H, bias=om.bias)
+        recon = torch.empty(B, Lq, Cv, dtype=f32, device=dev)
+        ops.softmax_tb_fwd(logits, Cv, recon, B, Lq, Cv)
+        ctx.mod, ctx.gen, ctx.z = mod, ws.generation, z
+        ctx.save_for_backward(recon)
+        return recon
+
+    @staticmethod
+    def backward(ctx, drecon):
+        mod, z = ctx.mod, ctx.z
+        (recon,) = ctx.saved_tensors
+        ws = mod._ws
+        if ws.generation != ctx.gen:
+            raise L.MvaeError("MolDecoder workspace was overwritten by a later forward; run backward before the next forward")
+        dev = z.device
+        f32 = torch.float32
+        g, dt = mod.gru, mod.compute_dtype
+        H, NL, o = g.hidden_size, g.num_layers, g.input_size
+        B = z.shape[0]
+        Lq = mod.repeat_vector.rep
+        om = mod.decoded_mean.module[0]
+        Cv = om.out_features
+        G4, TB = 4 * H, Lq * B
+        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
+        Cp = _pad(Cv, 8)
+        Bp = _pad(B, 4)
+        P = mod._packed
+        params = list(mod.parameters())
+        names = [n for n, _ in mod.named_parameters()]
+        total = sum(p.numel() for p in params)
+        gflat = torch.zeros(total, dtype=f32, device=dev)
+        grads, off = {}, 0
+        for n, p in zip(names, params):
+            grads[n] = gflat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        drecon = drecon.contiguous().float()
+        W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
+        hs = [W(f"hs{l}", (Lq, B, H), dt) for l in range(NL)]
+        hsT = [W(f"hsT{l}", (H, ldT), dt) for l in range(NL)]
+        cs = [W(f"cs{l}", (Lq, B, H)) for l in range(NL)]
+        gates = [W(f"gates{l}", (Lq, B, G4), dt) for l in range(NL)]
+        # K8 backward
+        dl = W("dl", (TB, Cp), dt); dlT = W("dlT", (Cv, ldT), dt)
+        ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
+        ops.gemm_nt(dlT, hsT[-1], grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
+        ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
+        dy = W("dy", (TB, H))
+        ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
+        # K7 backward
+        dG = [W(f"dG{l}", (Lq, B, G4), dt) for l in range(NL)]
+        dGT = [W(f"dGT{l}", (G4, ldT), dt) for l in range(NL)]
+        dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
+        ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dy, H, hs, H, cs, gates,
+                    dG, dGT, ldT, dstate)
+        for l in range(NL):
+            if Lq > 1:
+                ops.gemm_nt(dGT[l][:, B:], hsT[l], grads[f"gru.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
+            if l > 0:
+                ops.gemm_nt(dGT[l], hsT[l - 1], grads[f"gru.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
+            ops.rowsum(dGT[l], G4, TB, grads[f"gru.bias_ih_l{l}"])
+            grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
+        # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
+        dgx0 = W("dgx0", (B, G4))
+        ops.timesum(dG[0], Lq, B, G4, dgx0)
+        li = W("li", (B, o))
+        dgx0T, liT = W("dgx0T", (G4, Bp)), W("liT", (o, Bp))
+        ops.cast_transpose(dgx0, B, G4, dstT=dgx0T); ops.cast_transpose(li, B, o, dstT=liT)
+        ops.gemm_nt(dgx0T, liT, grads["gru.weight_ih_l0"], G4, o, Bp)
+        dli = W("dli", (B, o))
+        ops.gemm_nt(dgx0, P["Wih0T"], dli, B, o, G4)
+        # K6 backward
+        ops.selu_bwd(dli, li)
+        dliT, zT = W("dliT", (o, Bp)), W("zT", (o, Bp))
+        ops.cast_transpose(dli, B, o, dstT=dliT); ops.cast_transpose(z, B, o, dstT=zT)
+        ops.gemm_nt(dliT, zT, grads["latent_input.0.weight"], o, o, Bp)
+        ops.colsum(dli, B, o, grads["latent_input.0.bias"])
+        dz = torch.empty(B, o, dtype=f32, device=dev)
+        ops.gemm_nt(dli, P["WliT"], dz, B, o, o, ldb=P["WliT"].stride(0))
+        return (None, dz) + tuple(grads[n] for n in names)
+
+
+# ----------------------------------------------------------------------------------------------- VAE
+class MolecularVAE(nn.Module):
+    """models.py:97-106."""
+
+    def __init__(self, i=120, o=292, c=35, dtype=torch.bfloat16):
+        super().__init__()
+        self.encoder = MolEncoder(i=i, o=o, c=c)
+        self.decoder = MolDecoder(i=o, o=i, c=c, dtype=dtype)
+
+    def forward(self, x, eps=None):
+        x, mu, logvar = self.encoder(x, eps) if eps is not None else self.encoder(x)
+        return self.decoder(x), mu, logvar

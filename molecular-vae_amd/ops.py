@@ -1,0 +1,210 @@
+"""Tensor-level wrappers over the C ABI (include/mvae.h).  torch is plumbing only: device memory + streams.
+
+Every function launches HIP kernels on torch's current stream and raises on any non-zero status.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ptr, check, stream_ptr, dt_code
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+class Scratch:
+    """Grow-only byte scratch for split-K slabs and op-internal temporaries (one per device)."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes, device):
+        key = (device.type, device.index)
+        b = cls._bufs.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            cls._bufs[key] = b
+        return b
+
+
+def gemm_nt(A, B, out, M, N, K, lda=None, ldb=None, ldc=None, bias=None, act=L.ACT_NONE, accumulate=False):
+    """out[M,N] = act(A[M,K] . B[N,K]^T + bias).  A, B same dtype (f32 / bf16); out f32 or bf16."""
+    lib = L.load()
+    dt = dt_code(A.dtype)
+    assert B.dtype == A.dtype
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    ldc = out.stride(0) if ldc is None else ldc
+    need = lib.mvae_gemm_nt_workspace(M, N, K, dt)
+    ws = Scratch.get(need, A.device) if need else None
+    check(lib.mvae_gemm_nt(dt, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, dt_code(out.dtype), ptr(bias), act,
+                           1 if accumulate else 0, ptr(ws), need, stream_ptr()), "mvae_gemm_nt")
+    return out
+
+
+def cast_transpose(src, R, C_, dst=None, dstT=None, lds=None):
+    lib = L.load()
+    lds = src.stride(0) if lds is None else lds
+    d = dst if dst is not None else dstT
+    check(lib.mvae_cast_transpose(dt_code(src.dtype), dt_code(d.dtype), R, C_, ptr(src), lds,
+                                  ptr(dst), dst.stride(0) if dst is not None else 0,
+                                  ptr(dstT), dstT.stride(0) if dstT is not None else 0, stream_ptr()), "mvae_cast_transpose")
+
+
+def permute021(inp, out, N, A, Bd):
+    check(L.load().mvae_permute021(N, A, Bd, ptr(inp), ptr(out), stream_ptr()), "mvae_permute021")
+
+
+def gather_rows_tb(idx, table, out, B, Lq, nrows, W):
+    check(L.load().mvae_gather_rows_tb(ptr(idx), B, Lq, nrows, ptr(table), W, ptr(out), stream_ptr()), "mvae_gather_rows_tb")
+
+
+def scatter_rows_tb(idx, d, dtable, B, Lq, nrows, W):
+    lib = L.load()
+    need = lib.mvae_scatter_rows_tb_workspace(B, Lq, nrows, W)
+    ws = Scratch.get(need, d.device)
+    check(lib.mvae_scatter_rows_tb(dt_code(d.dtype), ptr(idx), B, Lq, nrows, ptr(d), W, W, ptr(dtable), ptr(ws), need,
+                                   stream_ptr()), "mvae_scatter_rows_tb")
+
+
+def rowsum(X, R, C_, out, ldx=None, accumulate=False):
+    check(L.load().mvae_rowsum(dt_code(X.dtype), R, C_, ptr(X), X.stride(0) if ldx is None else ldx, ptr(out),
+                               1 if accumulate else 0, stream_ptr()), "mvae_rowsum")
+
+
+def timesum(X, T, B, W, out):
+    check(L.load().mvae_timesum(dt_code(X.dtype), T, B, W, ptr(X), ptr(out), stream_ptr()), "mvae_timesum")
+
+
+def colsum(X, M, N, out, ldx=None):
+    check(L.load().mvae_colsum(M, N, ptr(X), X.stride(0) if ldx is None else ldx, ptr(out), stream_ptr()), "mvae_colsum")
+
+
+def selu_bwd(dy, y):
+    check(L.load().mvae_selu_bwd(dy.numel(), ptr(dy), ptr(y), stream_ptr()), "mvae_selu_bwd")
+
+
+def conv1d_selu_fwd(x, strides, B, Cin, W, Cout, k, w, bias, col, y):
+    lib = L.load()
+    need = lib.mvae_conv1d_selu_fwd_workspace(B, Cin, W, Cout, k)
+    ws = Scratch.get(need, x.device) if need else None
+    sb, sc, sw = strides
+    check(lib.mvae_conv1d_selu_fwd(B, Cin, W, Cout, k, ptr(x), sb, sc, sw, ptr(w), ptr(bias), ptr(col), ptr(y), Cout,
+                                   ptr(ws), need, stream_ptr()), "mvae_conv1d_selu_fwd")
+
+
+def conv1d_selu_bwd(B, Cin, W, Cout, k, dy, y, col, wT, ldwT, dw, db, dx, dx_strides):
+    lib = L.load()
+    need = lib.mvae_conv1d_selu_bwd_workspace(B, Cin, W, Cout, k)
+    ws = Scratch.get(need, dy.device)
+    sb, sc, sw = dx_strides
+    check(lib.mvae_conv1d_selu_bwd(B, Cin, W, Cout, k, ptr(dy), Cout, ptr(y), Cout, ptr(col), ptr(wT), ldwT, ptr(dw), ptr(db),
+                                   ptr(dx), sb, sc, sw, ptr(ws), need, stream_ptr()), "mvae_conv1d_selu_bwd")
+
+
+def lambda_fwd(mulv, eps, z, mu, logvar, B, o):
+    check(L.load().mvae_lambda_fwd(B, o, ptr(mulv), ptr(eps), ptr(z), ptr(mu), ptr(logvar), stream_ptr()), "mvae_lambda_fwd")
+
+
+def lambda_bwd(mulv, eps, dz, dmu, dlogvar, dmulv, B, o):
+    check(L.load().mvae_lambda_bwd(B, o, ptr(mulv), ptr(eps), ptr(dz), ptr(dmu), ptr(dlogvar), ptr(dmulv), stream_ptr()),
+          "mvae_lambda_bwd")
+
+
+def softmax_tb_fwd(logits, ldl, recon, B, Lq, C_):
+    check(L.load().mvae_softmax_tb_fwd(B, Lq, C_, ptr(logits), ldl, ptr(recon), stream_ptr()), "mvae_softmax_tb_fwd")
+
+
+def softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, C_):
+    check(L.load().mvae_softmax_tb_bwd(dt_code(dl.dtype), B, Lq, C_, ptr(recon), ptr(drecon), ptr(dl), dl.stride(0),
+                                       ptr(dlT), dlT.stride(0) if dlT is not None else 0, stream_ptr()), "mvae_softmax_tb_bwd")
+
+
+def bce_kl_loss_fwd(recon, target, mu, logvar, max_len, out3):
+    lib = L.load()
+    need = lib.mvae_bce_kl_loss_workspace(recon.numel(), mu.numel())
+    ws = Scratch.get(need, recon.device)
+    check(lib.mvae_bce_kl_loss_fwd(recon.numel(), ptr(recon), ptr(target), mu.numel(), ptr(mu), ptr(logvar), float(max_len),
+                                   ptr(out3), ptr(ws), need, stream_ptr()), "mvae_bce_kl_loss_fwd")
+
+
+def bce_kl_loss_bwd(recon, target, mu, logvar, max_len, grad_out, drecon, dmu, dlogvar):
+    check(L.load().mvae_bce_kl_loss_bwd(recon.numel(), ptr(recon), ptr(target), mu.numel(), ptr(mu), ptr(logvar), float(max_len),
+                                        ptr(grad_out), ptr(drecon), ptr(dmu), ptr(dlogvar), stream_ptr()), "mvae_bce_kl_loss_bwd")
+
+
+def _fill(arr, tensors):
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+
+
+def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, hsT, ldT, cs, gates,
+            x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None):
+    d = L.RnnFwdDesc()
+    NL = len(w_hh)
+    d.cell, d.dtype, d.layers, d.T, d.B, d.H, d.in0 = cell, dt_code(dtype), NL, T, B, H, in0
+    d.x0 = x0.data_ptr() if x0 is not None else None
+    d.x0_ld = x0_ld
+    d.add0 = add0.data_ptr() if add0 is not None else None
+    d.add0_tstride = add0_tstride
+    _fill(d.w_ih, w_ih); _fill(d.w_hh, w_hh); _fill(d.bias, bias)
+    for i in range(NL):
+        d.ldw_ih[i] = ldw_ih[i]
+        d.ldw_hh[i] = ldw_hh[i]
+    if h0 is not None:
+        _fill(d.h0, h0)
+    d.ldh0 = ldh0
+    d.lengths = lengths.data_ptr() if lengths is not None else None
+    _fill(d.hs, hs); d.ldh = ldh
+    if hsT is not None:
+        _fill(d.hsT, hsT)
+    d.ldT = ldT
+    if cs is not None:
+        _fill(d.cs, cs)
+    _fill(d.gates, gates)
+    check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
+
+
+def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dGT, ldT, dstate,
+            h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dGhT=None, dh0=None):
+    d = L.RnnBwdDesc()
+    NL = len(w_hhT)
+    d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
+    _fill(d.w_hhT, w_hhT); _fill(d.w_ihT, w_ihT)
+    for i in range(NL):
+        d.ldw_hhT[i] = ldw_hhT[i]
+        d.ldw_ihT[i] = ldw_ihT[i]
+    d.lengths = lengths.data_ptr() if lengths is not None else None
+    d.dy = dy.data_ptr() if dy is not None else None
+    d.dy_ld = dy_ld
+    if dh_last is not None:
+        _fill(d.dh_last, dh_last)
+    _fill(d.hs, hs); d.ldh = ldh
+    if h0 is not None:
+        _fill(d.h0, h0)
+    d.ldh0 = ldh0
+    if cs is not None:
+        _fill(d.cs, cs)
+    _fill(d.gates, gates); _fill(d.dG, dG)
+    if dGT is not None:
+        _fill(d.dGT, dGT)
+    d.ldT = ldT
+    if dGh is not None:
+        _fill(d.dGh, dGh)
+    if dGhT is not None:
+        _fill(d.dGhT, dGhT)
+    _fill(d.dstate, dstate)
+    if dh0 is not None:
+        _fill(d.dh0, dh0)
+    check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr()), "mvae_rnn_bwd")
+
+
+def sumsq(g, partial):
+    check(L.load().mvae_sumsq(g.numel(), ptr(g), ptr(partial), stream_ptr()), "mvae_sumsq")
+
+
+def clip_adam(p, g, m, v, partial, grad_scale, max_norm, lr, b1, b2, eps, step, norm_out):
+    check(L.load().mvae_clip_adam(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(partial), partial.numel(), float(grad_scale),
+                                  float(max_norm), float(lr), float(b1), float(b2), float(eps), int(step), ptr(norm_out),
+                                  stream_ptr()), "mvae_clip_adam")
