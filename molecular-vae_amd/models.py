@@ -498,7 +498,7 @@ class _DecoderFn(torch.autograd.Function):
         cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
         gates = [ws.get(f"gates{l}", (Lq, B, G4), dt, dev) for l in range(NL)]
         ops.rnn_fwd(L.CELL_LSTM, dt, Lq, B, H, gx0, 0, P["Wih"], [H] * NL, P["Whh"], [H] * NL, [None] + P["bias"][1:],
-                    hs, H, hsT, ldT, cs, gates)
+                    hs, H, hsT, ldT, cs, gates, tag="dec_lstm_fwd")
         # K8: output head + softmax over the class axis
         logits = ws.get("logits", (TB, Cv), f32, dev)
         ops.gemm_nt(hs[-1].view(TB, H), P["Wout"], logits, TB, Cv, H, bias=om.bias)
@@ -554,14 +554,15 @@ class _DecoderFn(torch.autograd.Function):
         dGT = [W(f"dGT{l}", (G4, ldT), dt) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dy, H, hs, H, cs, gates,
-                    dG, dGT, ldT, dstate)
-        for l in range(NL):
-            if Lq > 1:
-                ops.gemm_nt(dGT[l][:, B:], hsT[l], grads[f"gru.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
-            if l > 0:
-                ops.gemm_nt(dGT[l], hsT[l - 1], grads[f"gru.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
-            ops.rowsum(dGT[l], G4, TB, grads[f"gru.bias_ih_l{l}"])
-            grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
+                    dG, dGT, ldT, dstate, tag="dec_lstm_bwd")
+        with ops._Timed("dec_lstm_wgrad"):
+            for l in range(NL):
+                if Lq > 1:
+                    ops.gemm_nt(dGT[l][:, B:], hsT[l], grads[f"gru.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
+                if l > 0:
+                    ops.gemm_nt(dGT[l], hsT[l - 1], grads[f"gru.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
+                ops.rowsum(dGT[l], G4, TB, grads[f"gru.bias_ih_l{l}"])
+                grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
         dgx0 = W("dgx0", (B, G4))
         ops.timesum(dG[0], Lq, B, G4, dgx0)

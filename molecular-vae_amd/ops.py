@@ -14,6 +14,28 @@ def _pad(n, m):
     return (n + m - 1) // m * m
 
 
+# Optional device-side timing of tagged launch groups (bench.py's roofline leg): {tag: [(start, end) events]}.
+# Events are recorded on torch's current stream, which is the stream every kernel here is launched on.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if PROFILE is not None and self.tag:
+            self.s = torch.cuda.Event(enable_timing=True); self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None and self.tag:
+            self.e.record()
+            PROFILE.setdefault(self.tag, []).append((self.s, self.e))
+        return False
+
+
 class Scratch:
     """Grow-only byte scratch for split-K slabs and op-internal temporaries (one per device)."""
     _bufs = {}
@@ -140,7 +162,7 @@ def _fill(arr, tensors):
 
 
 def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, hsT, ldT, cs, gates,
-            x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None):
+            x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, tag=None):
     d = L.RnnFwdDesc()
     NL = len(w_hh)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H, d.in0 = cell, dt_code(dtype), NL, T, B, H, in0
@@ -163,11 +185,12 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
     if cs is not None:
         _fill(d.cs, cs)
     _fill(d.gates, gates)
-    check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
+    with _Timed(tag):
+        check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
 
 
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dGT, ldT, dstate,
-            h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dGhT=None, dh0=None):
+            h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dGhT=None, dh0=None, tag=None):
     d = L.RnnBwdDesc()
     NL = len(w_hhT)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
@@ -197,7 +220,8 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     _fill(d.dstate, dstate)
     if dh0 is not None:
         _fill(d.dh0, dh0)
-    check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr()), "mvae_rnn_bwd")
+    with _Timed(tag):
+        check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr()), "mvae_rnn_bwd")
 
 
 def sumsq(g, partial):

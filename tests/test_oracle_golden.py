@@ -85,3 +85,21 @@ def test_g3_moses_gru_path(golden_dir):
         n = float(np.sqrt((gr ** 2).sum()))
         assert abs(n - float(g["gnorm." + k])) <= 1e-8 * float(g["gnorm." + k]) + 1e-14, k
         assert rel(gr.reshape(-1)[:: max(1, gr.size // 64)][:64], g["gslice." + k]) < 1e-7, k
+
+
+def test_torch_port_matches_golden(golden_dir):
+    """The torch.nn CPU port timed by bench.py's cpu_baseline computes the fixture's numbers too."""
+    import torch
+    from oracle import torch_ref as TR
+    g = np.load(os.path.join(golden_dir, "g1_small.npz"))
+    m = TR.CpuPort(i=G1["i"], o=G1["o"], c=G1["c"], emb=G1["emb"], h_enc=G1["h_enc"], n_enc=G1["n_enc"],
+                   h_dec=G1["h_dec"], n_dec=G1["n_dec"]).double()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g1_params().items()})
+    idx = torch.from_numpy(g["idx"])
+    recon, mu, logvar = m(idx, torch.from_numpy(g["eps"]))
+    loss = TR.elbo(recon, torch.nn.functional.one_hot(idx, G1["c"]).double(), mu, logvar, G1["i"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-10 * abs(float(g["loss"]))
+    assert rel(mu.detach().numpy(), g["mu"]) < 1e-10 and rel(recon.detach().numpy(), g["recon"]) < 1e-9
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert rel(p.grad.numpy(), g["grad." + k]) < 2e-6, k
