@@ -48,6 +48,23 @@ def lstm_step_flops(B, T):
     return per_t_fwd * T / n_launch, per_t_bwd * T / n_launch, n_launch
 
 
+def host_cores(cap=32):
+    """Usable host cores: the affinity mask clipped by the cgroup CPU quota (an over-subscribed OpenMP team spins)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def log(msg):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,9 +101,14 @@ def main():
     def step():
         return mv.train_step(model, optimizer, loss_function, data, ohe)
 
-    for _ in range(args.warmup):
+    log(f"model built, B={B} dtype={args.dtype} world={world}")
+    for i in range(args.warmup):
         loss = step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log(f"first step done, loss={float(loss):.5f}")
     torch.cuda.synchronize()
+    log("warm-up done")
     if world > 1:
         dist.barrier()
     ops.PROFILE = {}
@@ -100,6 +122,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -131,8 +154,9 @@ def main():
                roofline=roofline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref
-        cores = len(os.sched_getaffinity(0))
-        r = torch_ref.time_cpu_training(batch=32, steps=args.cpu_steps, warmup=2, threads=cores)
+        cores = host_cores()
+        log(f"cpu baseline on {cores} threads ...")
+        r = torch_ref.time_cpu_training(batch=32, steps=args.cpu_steps, warmup=2, threads=cores, log=log)
         out["cpu_baseline"] = dict(value=round(r["molecules_per_s"], 2), unit="molecules/s", cores=r["threads"], kind="port",
                                    sample=f"{args.cpu_steps} train steps (after 2 warm-up) of the same model at batch 32 "
                                           f"(BASELINE.json configs[0]), torch.nn CPU modules, {r['s_per_step']:.2f} s/step")

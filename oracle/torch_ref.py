@@ -64,7 +64,7 @@ def elbo(recon, onehot, mu, logvar, max_len):
     return xent + kl
 
 
-def time_cpu_training(batch=32, steps=6, warmup=2, threads=None, seed=42, L=120, C=35):
+def time_cpu_training(batch=32, steps=6, warmup=2, threads=None, seed=42, L=120, C=35, log=None, budget_s=60.0):
     """Times `steps` train.py-style steps (fwd + loss + bwd + clip 3.0 + Adam 8e-4) on host cores."""
     if threads:
         torch.set_num_threads(threads)
@@ -86,6 +86,11 @@ def time_cpu_training(batch=32, steps=6, warmup=2, threads=None, seed=42, L=120,
         torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0)
         opt.step()
         losses.append(loss.item())
+        if log:
+            log(f"cpu step {s}: loss {losses[-1]:.4f}")
+        if t0 is not None and time.perf_counter() - t0 > budget_s and s + 1 < warmup + steps:
+            steps = s + 1 - warmup          # bounded sample: stop early on a slow host
+            break
     dt = time.perf_counter() - t0
     return dict(molecules_per_s=batch * steps / dt, s_per_step=dt / steps, threads=torch.get_num_threads(),
                 batch=batch, steps=steps, losses=losses)
