@@ -155,8 +155,9 @@ int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream);
 int mvae_rowsum(int dtype, int R, int C, const void* X, int64_t ldx, float* out, int accumulate, void* stream);
 /* out[b, :] = sum_t X[t, b, :]  (fp32 out): gradient of a time-invariant layer-0 input (models.py:163). */
 int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void* stream);
-/* out[n] = sum_m X[m, n] (fp32 in/out, deterministic): bias gradients of the dense / conv layers. */
-int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* stream);
+/* out[n] = sum_m X[m, n] (fp32 in/out, deterministic two-stage): bias gradients of the dense / conv layers. */
+size_t mvae_colsum_workspace(int M, int N);
+int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Conv1d(k) + bias + SELU, valid, stride 1 (K3; models.py:71-77 ConvSELU, :118-120, :129-131) as an

@@ -65,7 +65,8 @@ SIGNATURES = {
     "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),
     "mvae_rowsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp]),
     "mvae_timesum": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
-    "mvae_colsum": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
+    "mvae_colsum_workspace": (_sz, [_i, _i]),
+    "mvae_colsum": (_i, [_i, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
     "mvae_conv1d_selu_fwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "mvae_conv1d_selu_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "mvae_conv1d_selu_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),

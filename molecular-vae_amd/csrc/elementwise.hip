@@ -147,30 +147,56 @@ int launch_selu_bwd(long n, float* dy, const float* y, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------- reductions
-// out[n] = sum_m X[m, n]: block = 64 columns x 4 row-groups; fixed order.
-__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* X, long ldx, float* out) {
+// out[n] = sum_m X[m, n], two fixed-order stages: (column tile of 64) x (row chunk) partial sums, then a serial sum over chunks.
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(int M, int N, const float* X, long ldx, int rows_per_chunk, float* partial) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
   float v = 0.f;
-  if (c < N) for (int m = g; m < M; m += 4) v += X[(long)m * ldx + c];
+  if (c < N) for (int m = r0 + g; m < r1; m += 4) v += X[(long)m * ldx + c];
   red[g][threadIdx.x & 63] = v;
   __syncthreads();
-  if (g == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (g == 0 && c < N) partial[(long)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-int launch_colsum(int M, int N, const float* X, long ldx, float* out, hipStream_t st) {
+static int colsum_chunks(int M) { int c = (M + 511) / 512; if (c > 128) c = 128; if (c < 1) c = 1; return c; }
+size_t colsum_workspace_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
+int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
   if (N <= 0) return MVAE_OK;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, M, N, X, ldx, out);
+  const int chunks = colsum_chunks(M);
+  if (!ws || ws_bytes < colsum_workspace_bytes(M, N)) return MVAE_ERR_WORKSPACE;
+  const int rpc = (M + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, M, N, X, ldx, rpc, (float*)ws);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(grid_for(N)), dim3(256), 0, st, (const float*)ws, chunks, (long)N, out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
-// out[r] (+)= sum_c X[r, c]: one wave per row
+// out[r] (+)= sum_c X[r, c]: one wave per row, 16-byte loads when the row is 16-byte aligned
+template <typename T> __device__ __forceinline__ float sum_chunk16(const uint4& v);
+template <> __device__ __forceinline__ float sum_chunk16<float>(const uint4& v) {
+  return (__builtin_bit_cast(float, v.x) + __builtin_bit_cast(float, v.y)) + (__builtin_bit_cast(float, v.z) + __builtin_bit_cast(float, v.w));
+}
+template <> __device__ __forceinline__ float sum_chunk16<bf16_t>(const uint4& v) {
+  float a = 0.f;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a += __builtin_bit_cast(float, w[i] << 16) + __builtin_bit_cast(float, w[i] & 0xffff0000u);
+  return a;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void rowsum_kernel(int R, int C, const T* X, long ldx, float* out, int accumulate) {
+  constexpr int EPC = TT<T>::EPC;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   const T* p = X + (long)r * ldx;
   float v = 0.f;
-  for (int c = lane; c < C; c += 64) v += TT<T>::ld(p + c);
+  int c0 = 0;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    const int nch = C / EPC;
+    for (int i = lane; i < nch; i += 64) v += sum_chunk16<T>(*reinterpret_cast<const uint4*>(p + (long)i * EPC));
+    c0 = nch * EPC;
+  }
+  for (int c = c0 + lane; c < C; c += 64) v += TT<T>::ld(p + c);
   v = wave_sum(v);
   if (lane == 0) out[r] = accumulate ? out[r] + v : v;
 }
@@ -389,9 +415,10 @@ int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
-int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* stream) {
+size_t mvae_colsum_workspace(int M, int N) { return colsum_workspace_bytes(M, N); }
+int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream) {
   if (!X || !out || M < 0) return MVAE_ERR_INVALID;
-  return launch_colsum(M, N, X, ldx, out, (hipStream_t)stream);
+  return launch_colsum(M, N, X, ldx, out, ws, ws_bytes, (hipStream_t)stream);
 }
 int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream) {
   if (!dy || !y) return MVAE_ERR_INVALID;
@@ -420,7 +447,10 @@ size_t mvae_conv1d_selu_bwd_workspace(int B, int Cin, int W, int Cout, int k) {
   size_t dcol = (size_t)M * K * 4, dyT = (size_t)Cout * Mp * 4, colT = (size_t)K * Mp * 4;
   size_t g = gemm_nt_workspace_bytes(Cout, (int)K, (int)Mp, MVAE_F32);
   size_t g2 = gemm_nt_workspace_bytes((int)M, (int)K, Cout, MVAE_F32);
-  return dcol + dyT + colT + (g > g2 ? g : g2) + 256;
+  size_t g3 = colsum_workspace_bytes((int)M, Cout);
+  if (g2 > g) g = g2;
+  if (g3 > g) g = g3;
+  return dcol + dyT + colT + g + 256;
 }
 int mvae_conv1d_selu_bwd(int B, int Cin, int W, int Cout, int k, float* dy, int64_t lddy, const float* y, int64_t ldy, const float* col,
                          const float* wT, int64_t ldwT, float* dw, float* db, float* dx, int64_t dx_sb, int64_t dx_sc, int64_t dx_sw,
@@ -437,7 +467,7 @@ int mvae_conv1d_selu_bwd(int B, int Cin, int W, int Cout, int k, float* dy, int6
   void* gws = wp; size_t gws_bytes = ws_bytes - (size_t)(wp - reinterpret_cast<char*>(ws));
   int rc;
   if ((rc = launch_selu_bwd(M * Cout, dy, y, st))) return rc;                                  // dy <- dpre
-  if ((rc = launch_colsum((int)M, Cout, dy, Cout, db, st))) return rc;
+  if ((rc = launch_colsum((int)M, Cout, dy, Cout, db, gws, gws_bytes, st))) return rc;
   if ((rc = launch_cast_transpose(MVAE_F32, MVAE_F32, (int)M, Cout, dy, Cout, nullptr, 0, dyT, Mp, st))) return rc;
   if ((rc = launch_cast_transpose(MVAE_F32, MVAE_F32, (int)M, (int)K, col, K, nullptr, 0, colT, Mp, st))) return rc;
   // dw[Cout, K] = dpre^T . col

@@ -2,7 +2,7 @@
 // bf16 operands -> v_mfma_f32_16x16x32_bf16, f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32).
 // Tiles 128x128 or 64x64 per 256-thread workgroup, split-K with a deterministic fp32 slab reduction when the
 // output alone cannot fill 256 CUs.  Blocks are remapped so that consecutive tiles of one XCD share A rows.
-#include "tile.hpp"
+#include "tile_pipe.hpp"
 #include "kernels.hpp"
 
 struct GemmArgs {
@@ -30,7 +30,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool PIPE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
@@ -57,7 +57,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < NI; ++j) brow[j] = wn * WN + j * 16;
 
-  tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, kbeg, kend, wm * WM, brow, acc, tid);
+  if constexpr (PIPE) {
+    constexpr int NBUF = 4;
+    PipeSeg<BM, BN> s0, s1;
+    const uint32_t sz = (uint32_t)sizeof(T);
+    auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < p.M ? (uint32_t)gm * (uint32_t)p.lda * sz : PIPE_OOB; };
+    auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < p.N ? (uint32_t)gn * (uint32_t)p.ldb * sz : PIPE_OOB; };
+    const uint32_t bytesA = (uint32_t)((long)p.M * p.lda * sz - kbeg * sz), bytesB = (uint32_t)((long)p.N * p.ldb * sz - kbeg * sz);
+    pipe_seg_init<T, BM, BN>(s0, A + kbeg, bytesA, B + kbeg, bytesB, offA, offB, (int)(kend - kbeg), tid);
+    s1 = s0; s1.nk = 0;
+    tile_gemm_pipe<T, BM, BN, MI, NI, NBUF, 16>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+  } else {
+    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, kbeg, kend, wm * WM, brow, acc, tid);
+  }
 
   const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
@@ -146,14 +158,27 @@ int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, cons
     p.partial = reinterpret_cast<float*>(ws);
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(256);
-  const size_t lds = (size_t)2 * (pl.bm + pl.bm) * KB;
+  const int sz = (dtype == MVAE_BF16) ? 2 : 4, ke = KB / sz;
+  // deep-pipelined LDS-direct path: whole K-steps only, 16-byte aligned rows, operands < 2 GiB
+  const bool pipe = (K % ke == 0) && (pl.kper % ke == 0) && (lda % (16 / sz) == 0) && (ldb % (16 / sz) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0) &&
+                    ((long)M * lda * sz < (1L << 31)) && ((long)N * ldb * sz < (1L << 31)) && K >= 4 * ke;
+  const size_t lds = (size_t)(pipe ? 4 : 2) * (pl.bm + pl.bm) * KB;
+#define MVAE_GEMM_LAUNCH(TT_, BM_, PIPE_)                                                             \
+  do {                                                                                                \
+    auto kern = gemm_nt_kernel<TT_, BM_, BM_, PIPE_>;                                                 \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                \
+  } while (0)
   if (dtype == MVAE_BF16) {
-    if (pl.bm == 128) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128, 128>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 64, 64>), grid, block, lds, st, p);
+    if (pl.bm == 128) { if (pipe) MVAE_GEMM_LAUNCH(bf16_t, 128, true); else MVAE_GEMM_LAUNCH(bf16_t, 128, false); }
+    else { if (pipe) MVAE_GEMM_LAUNCH(bf16_t, 64, true); else MVAE_GEMM_LAUNCH(bf16_t, 64, false); }
   } else {
-    if (pl.bm == 128) hipLaunchKernelGGL((gemm_nt_kernel<float, 128, 128>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<float, 64, 64>), grid, block, lds, st, p);
+    if (pl.bm == 128) { if (pipe) MVAE_GEMM_LAUNCH(float, 128, true); else MVAE_GEMM_LAUNCH(float, 128, false); }
+    else { if (pipe) MVAE_GEMM_LAUNCH(float, 64, true); else MVAE_GEMM_LAUNCH(float, 64, false); }
   }
+#undef MVAE_GEMM_LAUNCH
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;

@@ -9,5 +9,6 @@ int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, cons
                    int c_dtype, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, long lds_, void* dst, long ldd, void* dstT,
                           long ldt, hipStream_t st);
-int launch_colsum(int M, int N, const float* X, long ldx, float* out, hipStream_t st);
+size_t colsum_workspace_bytes(int M, int N);
+int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_selu_bwd(long n, float* dy, const float* y, hipStream_t st);

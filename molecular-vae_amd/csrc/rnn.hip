@@ -3,7 +3,7 @@
 // holds the 4 gate pre-activations of the same (batch row, hidden unit) in one lane, so the gate
 // non-linearities and the state update run in the epilogue (models.py:128,164 nn.LSTM).
 // Backward cell update = tile loop over (dG_{t+1} . W_hh, dG^{l+1}_t . W_ih^{l+1}) + gate derivative epilogue.
-#include "tile.hpp"
+#include "tile_pipe.hpp"
 #include "kernels.hpp"
 
 struct StepTaskF {
@@ -34,16 +34,22 @@ __device__ __forceinline__ void store_rows4(T* rowbase, long col0, const float (
   }
 }
 
-template <typename T, int BM, int BJ>
+__device__ __forceinline__ int xcd_remap_r(int bid, int n) {   // contiguous tile ranges per XCD (see gemm.hip)
+  const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <typename T, int BM, int BJ, bool PIPE>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(BJ == 32, "one 16-wide hidden sub-tile per wave and gate");
   constexpr int BN = 4 * BJ, WM = BM / 2, MI = WM / 16, NI = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wj = wave & 1;
   const int per_task = p.tiles_m * p.tiles_j;
-  const int task = blockIdx.x / per_task;
-  const int rem = blockIdx.x - task * per_task;
-  const int tj = rem / p.tiles_m, tm = rem - tj * p.tiles_m;   // consecutive blocks share the weight panel
+  const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task);
+  const int task = bid / per_task;
+  const int rem = bid - task * per_task;
+  const int tj = rem / p.tiles_m, tm = rem - tj * p.tiles_m;   // tiles sharing a weight panel are neighbours on one XCD
   const StepTaskF& q = p.t[task];
   const int m0 = tm * BM, j0 = tj * BJ, H = p.H, B = p.B;
 
@@ -56,21 +62,39 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
 #pragma unroll
   for (int g = 0; g < NI; ++g) brow[g] = g * BJ + wj * 16;
 
+  if constexpr (PIPE) {
+    PipeSeg<BM, BN> s0, s1;
+    const uint32_t sz = (uint32_t)sizeof(T);
+    {
+      const uint32_t lda = (uint32_t)q.lda0 * sz, ldw = (uint32_t)q.ldw0 * sz;
+      auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
+      auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
+      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)(4 * H) * ldw, offA, offB, q.K0, tid);
+    }
+    {
+      const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
+      auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
+      auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
+      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)(4 * H) * ldw, offA, offB, q.K1, tid);
+    }
+    tile_gemm_pipe<T, BM, BN, MI, NI, 4, BJ>(smem, s0, s1, wm * WM, wj * 16, acc, tid);
+  } else {
   if (q.A0 != nullptr) {
-    const T* A = reinterpret_cast<const T*>(q.A0);
-    const T* W = reinterpret_cast<const T*>(q.W0);
-    const long lda = q.lda0, ldw = q.ldw0;
-    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
-    auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
-    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
-  }
-  if (q.A1 != nullptr) {
-    const T* A = reinterpret_cast<const T*>(q.A1);
-    const T* W = reinterpret_cast<const T*>(q.W1);
-    const long lda = q.lda1, ldw = q.ldw1;
-    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
-    auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
-    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+      const T* A = reinterpret_cast<const T*>(q.A0);
+      const T* W = reinterpret_cast<const T*>(q.W0);
+      const long lda = q.lda0, ldw = q.ldw0;
+      auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+      auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
+      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
+    }
+    if (q.A1 != nullptr) {
+      const T* A = reinterpret_cast<const T*>(q.A1);
+      const T* W = reinterpret_cast<const T*>(q.W1);
+      const long lda = q.lda1, ldw = q.ldw1;
+      auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+      auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
+      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+    }
   }
 
   const int j = j0 + wj * 16 + (lane & 15);
@@ -122,14 +146,15 @@ struct StepTaskB {
 };
 struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_n; };
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool PIPE>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int per_task = p.tiles_m * p.tiles_n;
-  const int task = blockIdx.x / per_task;
-  const int rem = blockIdx.x - task * per_task;
+  const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task);
+  const int task = bid / per_task;
+  const int rem = bid - task * per_task;
   const int tn = rem / p.tiles_m, tm = rem - tn * p.tiles_m;
   const StepTaskB& q = p.t[task];
   const int m0 = tm * BM, n0 = tn * BN, H = p.H, B = p.B;
@@ -143,21 +168,39 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
 #pragma unroll
   for (int n = 0; n < NI; ++n) brow[n] = wn * WN + n * 16;
 
+  if constexpr (PIPE) {
+    PipeSeg<BM, BN> s0, s1;
+    const uint32_t sz = (uint32_t)sizeof(T);
+    {
+      const uint32_t lda = (uint32_t)q.lda0 * sz, ldw = (uint32_t)q.ldw0 * sz;
+      auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
+      auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
+      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)H * ldw, offA, offB, q.K0, tid);
+    }
+    {
+      const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
+      auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
+      auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
+      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, q.K1, tid);
+    }
+    tile_gemm_pipe<T, BM, BN, MI, NI, 4, 16>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+  } else {
   if (q.A0 != nullptr) {
-    const T* A = reinterpret_cast<const T*>(q.A0);
-    const T* W = reinterpret_cast<const T*>(q.W0);
-    const long lda = q.lda0, ldw = q.ldw0;
-    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
-    auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
-    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
-  }
-  if (q.A1 != nullptr) {
-    const T* A = reinterpret_cast<const T*>(q.A1);
-    const T* W = reinterpret_cast<const T*>(q.W1);
-    const long lda = q.lda1, ldw = q.ldw1;
-    auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
-    auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
-    tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+      const T* A = reinterpret_cast<const T*>(q.A0);
+      const T* W = reinterpret_cast<const T*>(q.W0);
+      const long lda = q.lda0, ldw = q.ldw0;
+      auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+      auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
+      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
+    }
+    if (q.A1 != nullptr) {
+      const T* A = reinterpret_cast<const T*>(q.A1);
+      const T* W = reinterpret_cast<const T*>(q.W1);
+      const long lda = q.lda1, ldw = q.ldw1;
+      auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+      auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
+      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+    }
   }
 
   const int lq = lane >> 4;
@@ -207,6 +250,14 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host drivers
+#define MVAE_STEP_LAUNCH(KERN)                                                                                     \
+  do {                                                                                                               \
+    auto kern = KERN;                                                                                                \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
+  } while (0)
+
 static inline const char* adv(const void* p, long elems, int dtype) {
   return reinterpret_cast<const char*>(p) + elems * (dtype == MVAE_BF16 ? 2 : 4);
 }
@@ -228,6 +279,14 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (!d->x0 && !d->add0) return MVAE_ERR_INVALID;
   if (d->ldh % epc) return MVAE_ERR_INVALID;
   const int BM = (B > 64 && ((B + 127) / 128) * ((H + 31) / 32) * NL >= 256) ? 128 : 64;
+  const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
+  // deep-pipelined LDS-direct path: whole K-steps, 16-byte aligned rows, operands < 2 GiB
+  bool pipe = (H % ke == 0) && (d->ldh % (16 / sz) == 0) && ((long)B * d->ldh * sz < (1L << 31)) && (!d->x0 || (d->in0 % ke == 0 && d->x0_ld % (16 / sz) == 0)) &&
+              (!d->h0[0] || d->ldh0 % (16 / sz) == 0);
+  for (int l = 0; l < NL; ++l) {
+    if ((4L * H) * d->ldw_hh[l] * sz >= (1L << 31) || d->ldw_hh[l] % (16 / sz)) pipe = false;
+    if ((l > 0 || d->x0) && ((4L * H) * d->ldw_ih[l] * sz >= (1L << 31) || d->ldw_ih[l] % (16 / sz))) pipe = false;
+  }
   StepArgsF a;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + 31) / 32;
   for (int dd = 0; dd < T + NL - 1; ++dd) {
@@ -258,13 +317,13 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_j), block(256);
-    const size_t lds = (size_t)2 * (BM + 128) * KB;
+    const size_t lds = (size_t)(pipe ? 4 : 2) * (BM + 128) * KB;
     if (dt == MVAE_BF16) {
-      if (BM == 128) hipLaunchKernelGGL((lstm_step_fwd_kernel<bf16_t, 128, 32>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((lstm_step_fwd_kernel<bf16_t, 64, 32>), grid, block, lds, st, a);
+      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 32, false>)); }
+      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 64, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 64, 32, false>)); }
     } else {
-      if (BM == 128) hipLaunchKernelGGL((lstm_step_fwd_kernel<float, 128, 32>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((lstm_step_fwd_kernel<float, 64, 32>), grid, block, lds, st, a);
+      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 128, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 128, 32, false>)); }
+      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 64, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 64, 32, false>)); }
     }
   }
   MVAE_CHECK_HIP(hipGetLastError());
@@ -286,6 +345,12 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   }
   if ((4L * H) % epc) return MVAE_ERR_INVALID;
   const int BM = (B > 64 && ((B + 127) / 128) * ((H + 63) / 64) * NL >= 200) ? 128 : 64;
+  const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
+  bool pipe = ((4 * H) % ke == 0) && ((long)B * 4 * H * sz < (1L << 31));
+  for (int l = 0; l < NL; ++l) {
+    if ((long)H * d->ldw_hhT[l] * sz >= (1L << 31) || d->ldw_hhT[l] % (16 / sz)) pipe = false;
+    if (l > 0 && ((long)H * d->ldw_ihT[l] * sz >= (1L << 31) || d->ldw_ihT[l] % (16 / sz))) pipe = false;
+  }
   StepArgsB a;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + 63) / 64;
   for (int e = T + NL - 2; e >= 0; --e) {
@@ -309,13 +374,13 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n), block(256);
-    const size_t lds = (size_t)2 * (BM + 64) * KB;
+    const size_t lds = (size_t)(pipe ? 4 : 2) * (BM + 64) * KB;
     if (dt == MVAE_BF16) {
-      if (BM == 128) hipLaunchKernelGGL((lstm_step_bwd_kernel<bf16_t, 128, 64>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((lstm_step_bwd_kernel<bf16_t, 64, 64>), grid, block, lds, st, a);
+      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, false>)); }
+      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 64, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 64, 64, false>)); }
     } else {
-      if (BM == 128) hipLaunchKernelGGL((lstm_step_bwd_kernel<float, 128, 64>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((lstm_step_bwd_kernel<float, 64, 64>), grid, block, lds, st, a);
+      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 128, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 128, 64, false>)); }
+      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 64, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 64, 64, false>)); }
     }
   }
   MVAE_CHECK_HIP(hipGetLastError());

@@ -100,7 +100,10 @@ def timesum(X, T, B, W, out):
 
 
 def colsum(X, M, N, out, ldx=None):
-    check(L.load().mvae_colsum(M, N, ptr(X), X.stride(0) if ldx is None else ldx, ptr(out), stream_ptr()), "mvae_colsum")
+    lib = L.load()
+    need = lib.mvae_colsum_workspace(M, N)
+    ws = Scratch.get(need, X.device)
+    check(lib.mvae_colsum(M, N, ptr(X), X.stride(0) if ldx is None else ldx, ptr(out), ptr(ws), need, stream_ptr()), "mvae_colsum")
 
 
 def selu_bwd(dy, y):

@@ -25,7 +25,7 @@ def t_gemm():
     rs = np.random.RandomState(0)
     for dt, tol in ((torch.float32, 2e-6), (torch.bfloat16, 2e-2)):
         for (M, N, K) in ((64, 64, 64), (128, 128, 256), (300, 200, 96), (35, 1024, 2048), (17, 9, 40), (4096, 1024, 1024),
-                          (288, 72, 2880), (1, 5, 8), (512, 4096, 292 if dt == torch.float32 else 296)):
+                          (288, 72, 2880), (1, 5, 8), (300, 200, 512), (130, 70, 4096), (4096, 1024, 61440 // 8), (512, 4096, 292 if dt == torch.float32 else 296)):
             A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(dev).to(dt)
             B = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).to(dev).to(dt)
             bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(dev)
@@ -151,6 +151,15 @@ def t_small_ops():
         ref_dl = p2 * (dp - (dp * p2).sum(1, keepdims=True))
         print(f"  softmax bwd {dt}: rel={rel(dl[:, :C].float().cpu().numpy(), ref_dl):.3e} pad0={float(dl[:, C:].abs().sum())} "
               f"T rel={rel(dlT[:, :Lq * B].float().cpu().numpy(), ref_dl.T):.3e}")
+    X = rs.standard_normal((1000, 150)).astype(np.float32)
+    out = torch.zeros(150, device=dev)
+    ops.colsum(t(X), 1000, 150, out)
+    print(f"  colsum rel={rel(out.cpu().numpy(), X.astype(np.float64).sum(0)):.3e}")
+    for dt in (torch.float32, torch.bfloat16):
+        Xt = t(X).to(dt)
+        out = torch.zeros(1000, device=dev)
+        ops.rowsum(Xt[:, :144], 1000, 144, out, ldx=150)
+        print(f"  rowsum {dt} rel={rel(out.cpu().numpy(), Xt[:, :144].double().cpu().numpy().sum(1)):.3e}")
     # adam
     n = 200000
     p0 = rs.standard_normal(n); g0 = rs.standard_normal(n) * 0.05
@@ -186,7 +195,11 @@ def t_model(name, dims, params, idx, eps, dtype, tol):
 def main():
     print(torch.cuda.get_device_name(0), flush=True)
     steps = [t_gemm, t_cast_transpose, lambda: t_lstm(torch.float32, 2e-5), lambda: t_lstm(torch.bfloat16, 3e-2),
-             lambda: t_lstm(torch.float32, 2e-5, T=5, B=70, H=72, NL=3, In=8), t_small_ops]
+             lambda: t_lstm(torch.float32, 2e-5, T=5, B=70, H=72, NL=3, In=8),
+             lambda: t_lstm(torch.bfloat16, 3e-2, T=6, B=130, H=128, NL=3, In=8),      # LDS-direct pipelined path, ragged rows
+             lambda: t_lstm(torch.float32, 2e-5, T=4, B=200, H=64, NL=2, In=8),        # pipelined path, f32
+             lambda: t_lstm(torch.bfloat16, 3e-2, T=3, B=256, H=192, NL=4, In=8),
+             t_small_ops]
     for s in steps:
         try:
             s()
