@@ -125,7 +125,7 @@ int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
  * and, in the epilogue, the gate derivative dG^{l}_t (pre-activation gradient) and dc_{t-1}.
  *   w_hhT[l] [H, G*H], w_ihT[l] [in, G*H]: TRANSPOSED weights (K-contiguous for this contraction).
  *   dy       [T][B][H] fp32 gradient w.r.t. the stack output (row stride dy_ld).
- *   dG[l]    [T][B][G*H] dtype  (out)  pre-activation gradients; dG[0] is also the gradient of add0.
+ *   dG[l]    [T][B][ldg]  dtype  (out)  pre-activation gradients (G*H valid columns); dG[0] is also the gradient of add0.
  *   dGT[l]   [G*H][ldT]  dtype  (out, may be NULL)  transposed copy feeding the weight-gradient GEMMs
  *                               (GRU: dGT holds the W_ih-side gradient rows [r,z,n]; dGhT the W_hh-side).
  *   dcs      2*layers fp32 [B,H] scratch (ping-pong dc), dh_carry: GRU scratch.
@@ -142,7 +142,7 @@ typedef struct {
   const void* h0[MVAE_MAX_LAYERS]; int64_t ldh0;
   const float* cs[MVAE_MAX_LAYERS];
   const void* gates[MVAE_MAX_LAYERS];
-  void* dG[MVAE_MAX_LAYERS];
+  void* dG[MVAE_MAX_LAYERS]; int64_t ldg;                                  /* row stride of dG (>= G*H; pad it off powers of two) */
   void* dGT[MVAE_MAX_LAYERS]; int64_t ldT;
   void* dGh[MVAE_MAX_LAYERS]; void* dGhT[MVAE_MAX_LAYERS];               /* GRU only */
   float* dstate[MVAE_MAX_LAYERS];                                         /* fp32 [2][B][H] ping-pong: LSTM dc, GRU dh carry */

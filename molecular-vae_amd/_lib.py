@@ -43,7 +43,7 @@ class RnnBwdDesc(C.Structure):
                 ("h0", _vp * MAX_LAYERS), ("ldh0", _i64),
                 ("cs", _vp * MAX_LAYERS),
                 ("gates", _vp * MAX_LAYERS),
-                ("dG", _vp * MAX_LAYERS),
+                ("dG", _vp * MAX_LAYERS), ("ldg", _i64),
                 ("dGT", _vp * MAX_LAYERS), ("ldT", _i64),
                 ("dGh", _vp * MAX_LAYERS), ("dGhT", _vp * MAX_LAYERS),
                 ("dstate", _vp * MAX_LAYERS),

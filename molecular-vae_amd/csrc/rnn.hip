@@ -5,6 +5,7 @@
 // Backward cell update = tile loop over (dG_{t+1} . W_hh, dG^{l+1}_t . W_ih^{l+1}) + gate derivative epilogue.
 #include "tile_pipe.hpp"
 #include "kernels.hpp"
+#include <stdlib.h>
 
 struct StepTaskF {
   const void *A0, *A1, *W0, *W1;
@@ -17,7 +18,7 @@ struct StepTaskF {
   void* hT_out; long ldT; long tcol;
   void* g_out;
 };
-struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_j; };
+struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_j, dbg; };
 
 template <typename T> struct Vec4;   // 4 consecutive elements as one store
 template <> struct Vec4<float> { typedef float4 type; static __device__ __forceinline__ float4 make(float a, float b, float c, float d) { return make_float4(a, b, c, d); } };
@@ -39,8 +40,9 @@ __device__ __forceinline__ int xcd_remap_r(int bid, int n) {   // contiguous til
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <typename T, int BM, int BJ, bool PIPE>
+template <typename T, int BM, int BJ, int NBUF>   // NBUF == 0: generic register-staged path (any shape)
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
+  constexpr bool PIPE = NBUF > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(BJ == 32, "one 16-wide hidden sub-tile per wave and gate");
   constexpr int BN = 4 * BJ, WM = BM / 2, MI = WM / 16, NI = 4;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
       auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)(4 * H) * ldw, offA, offB, q.K1, tid);
     }
-    tile_gemm_pipe<T, BM, BN, MI, NI, 4, BJ>(smem, s0, s1, wm * WM, wj * 16, acc, tid);
+    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), BJ>(smem, s0, s1, wm * WM, wj * 16, acc, tid);
   } else {
   if (q.A0 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A0);
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
     }
   }
 
+  if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.t[0].c_out[0] = 1.f; return; }   // tuning hook: main loop only
   const int j = j0 + wj * 16 + (lane & 15);
   if (j >= H) return;
   const int lq = lane >> 4;
@@ -142,12 +145,13 @@ struct StepTaskB {
   const float* dy; long dy_ld;
   const void* gates; const float* c; const float* c_prev;
   const float* dc_in; float* dc_out;
-  void* dG; void* dGT; long ldT; long tcol;
+  void* dG; long ldg; void* dGT; long ldT; long tcol;
 };
-struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_n; };
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_n, dbg; };
 
-template <typename T, int BM, int BN, bool PIPE>
+template <typename T, int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
+  constexpr bool PIPE = NBUF > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, q.K1, tid);
     }
-    tile_gemm_pipe<T, BM, BN, MI, NI, 4, 16>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), 16>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
   } else {
   if (q.A0 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A0);
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
     }
   }
 
+  if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.t[0].dc_out[0] = 1.f; return; }   // tuning hook: main loop only
   const int lq = lane >> 4;
   const T* gates = reinterpret_cast<const T*>(q.gates);
   T* dG = reinterpret_cast<T*>(q.dG);
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
         vf[r] = dc * cp * fg * (1.f - fg);
         vg[r] = dc * ig * (1.f - gg * gg);
         vo[r] = d_o * og * (1.f - og);
-        T* d4 = dG + (long)row * 4 * H + j;
+        T* d4 = dG + (long)row * q.ldg + j;
         TT<T>::st(d4, vi[r]); TT<T>::st(d4 + H, vf[r]); TT<T>::st(d4 + 2 * H, vg[r]); TT<T>::st(d4 + 3 * H, vo[r]);
       }
       if (dGT && nvalid > 0) {
@@ -258,6 +263,12 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
   } while (0)
 
+// tuning knobs (read once): MVAE_NBUF_FWD / MVAE_NBUF_BWD = LDS ring depth, MVAE_BM = force row-tile, MVAE_DBG bit0 = skip epilogue
+static int tune_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 static inline const char* adv(const void* p, long elems, int dtype) {
   return reinterpret_cast<const char*>(p) + elems * (dtype == MVAE_BF16 ? 2 : 4);
 }
@@ -278,7 +289,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (d->x0 && (!d->w_ih[0] || d->in0 < 1)) return MVAE_ERR_INVALID;
   if (!d->x0 && !d->add0) return MVAE_ERR_INVALID;
   if (d->ldh % epc) return MVAE_ERR_INVALID;
-  const int BM = (B > 64 && ((B + 127) / 128) * ((H + 31) / 32) * NL >= 256) ? 128 : 64;
+  const int BM = tune_int("MVAE_BM", (B > 64 && ((B + 127) / 128) * ((H + 31) / 32) * NL >= 256) ? 128 : 64);
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
   // deep-pipelined LDS-direct path: whole K-steps, 16-byte aligned rows, operands < 2 GiB
   bool pipe = (H % ke == 0) && (d->ldh % (16 / sz) == 0) && ((long)B * d->ldh * sz < (1L << 31)) && (!d->x0 || (d->in0 % ke == 0 && d->x0_ld % (16 / sz) == 0)) &&
@@ -317,14 +328,18 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_j), block(256);
-    const size_t lds = (size_t)(pipe ? 4 : 2) * (BM + 128) * KB;
+    const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", BM == 128 ? 4 : 4) : 0;
+    const size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 128) * KB;
+    a.dbg = tune_int("MVAE_DBG", 0);
+#define FWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
     if (dt == MVAE_BF16) {
-      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 32, false>)); }
-      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 64, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 64, 32, false>)); }
+      FWD_CASE(bf16_t, 128, 0) FWD_CASE(bf16_t, 128, 3) FWD_CASE(bf16_t, 128, 4) FWD_CASE(bf16_t, 128, 5)
+      FWD_CASE(bf16_t, 64, 0) FWD_CASE(bf16_t, 64, 3) FWD_CASE(bf16_t, 64, 4) FWD_CASE(bf16_t, 64, 5)
     } else {
-      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 128, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 128, 32, false>)); }
-      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 64, 32, true>)); else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<float, 64, 32, false>)); }
+      FWD_CASE(float, 128, 0) FWD_CASE(float, 128, 4) FWD_CASE(float, 64, 0) FWD_CASE(float, 64, 4)
     }
+#undef FWD_CASE
+    return MVAE_ERR_UNSUPPORTED;
   }
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
@@ -343,10 +358,11 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     if (l > 0 && !d->w_ihT[l]) return MVAE_ERR_INVALID;
     if (d->ldw_hhT[l] % epc || (l > 0 && d->ldw_ihT[l] % epc)) return MVAE_ERR_INVALID;
   }
-  if ((4L * H) % epc) return MVAE_ERR_INVALID;
-  const int BM = (B > 64 && ((B + 127) / 128) * ((H + 63) / 64) * NL >= 200) ? 128 : 64;
+  const long ldg = d->ldg;
+  if (ldg < 4L * H || ldg % epc) return MVAE_ERR_INVALID;
+  const int BM = tune_int("MVAE_BM", (B > 64 && ((B + 127) / 128) * ((H + 63) / 64) * NL >= 200) ? 128 : 64);
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
-  bool pipe = ((4 * H) % ke == 0) && ((long)B * 4 * H * sz < (1L << 31));
+  bool pipe = ((4 * H) % ke == 0) && ((long)B * ldg * sz < (1L << 31)) && (ldg % (16 / sz) == 0);
   for (int l = 0; l < NL; ++l) {
     if ((long)H * d->ldw_hhT[l] * sz >= (1L << 31) || d->ldw_hhT[l] % (16 / sz)) pipe = false;
     if (l > 0 && ((long)H * d->ldw_ihT[l] * sz >= (1L << 31) || d->ldw_ihT[l] % (16 / sz))) pipe = false;
@@ -359,29 +375,33 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       const int t = e - l;
       if (t < 0 || t >= T) continue;
       StepTaskB& q = a.t[n++];
-      q.A0 = (t < T - 1) ? adv(d->dG[l], (long)(t + 1) * B * 4 * H, dt) : nullptr;
-      q.lda0 = 4L * H; q.K0 = 4 * H; q.W0 = d->w_hhT[l]; q.ldw0 = d->ldw_hhT[l];
-      q.A1 = (l < NL - 1) ? adv(d->dG[l + 1], (long)t * B * 4 * H, dt) : nullptr;
-      q.lda1 = 4L * H; q.K1 = 4 * H; q.W1 = (l < NL - 1) ? d->w_ihT[l + 1] : nullptr; q.ldw1 = (l < NL - 1) ? d->ldw_ihT[l + 1] : 0;
+      q.A0 = (t < T - 1) ? adv(d->dG[l], (long)(t + 1) * B * ldg, dt) : nullptr;
+      q.lda0 = ldg; q.K0 = 4 * H; q.W0 = d->w_hhT[l]; q.ldw0 = d->ldw_hhT[l];
+      q.A1 = (l < NL - 1) ? adv(d->dG[l + 1], (long)t * B * ldg, dt) : nullptr;
+      q.lda1 = ldg; q.K1 = 4 * H; q.W1 = (l < NL - 1) ? d->w_ihT[l + 1] : nullptr; q.ldw1 = (l < NL - 1) ? d->ldw_ihT[l + 1] : 0;
       q.dy = (l == NL - 1) ? d->dy + (long)t * B * d->dy_ld : nullptr; q.dy_ld = d->dy_ld;
       q.gates = adv(d->gates[l], (long)t * B * 4 * H, dt);
       q.c = d->cs[l] + (long)t * B * H;
       q.c_prev = (t > 0) ? d->cs[l] + (long)(t - 1) * B * H : nullptr;
       q.dc_in = (t < T - 1) ? d->dstate[l] + (long)((t + 1) & 1) * B * H : nullptr;
       q.dc_out = d->dstate[l] + (long)(t & 1) * B * H;
-      q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * 4 * H, dt));
+      q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * ldg, dt)); q.ldg = ldg;
       q.dGT = d->dGT[l]; q.ldT = d->ldT; q.tcol = (long)t * B;
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n), block(256);
-    const size_t lds = (size_t)(pipe ? 4 : 2) * (BM + 64) * KB;
+    const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
+    const size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 64) * KB;
+    a.dbg = tune_int("MVAE_DBG", 0);
+#define BWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<TT_, BM_, 64, NB_>)); continue; }
     if (dt == MVAE_BF16) {
-      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, false>)); }
-      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 64, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 64, 64, false>)); }
+      BWD_CASE(bf16_t, 128, 0) BWD_CASE(bf16_t, 128, 3) BWD_CASE(bf16_t, 128, 4) BWD_CASE(bf16_t, 128, 5) BWD_CASE(bf16_t, 128, 6)
+      BWD_CASE(bf16_t, 64, 0) BWD_CASE(bf16_t, 64, 3) BWD_CASE(bf16_t, 64, 4) BWD_CASE(bf16_t, 64, 5) BWD_CASE(bf16_t, 64, 6)
     } else {
-      if (BM == 128) { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 128, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 128, 64, false>)); }
-      else { if (pipe) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 64, 64, true>)); else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<float, 64, 64, false>)); }
+      BWD_CASE(float, 128, 0) BWD_CASE(float, 128, 4) BWD_CASE(float, 64, 0) BWD_CASE(float, 64, 4)
     }
+#undef BWD_CASE
+    return MVAE_ERR_UNSUPPORTED;
   }
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;

@@ -47,21 +47,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int BM, int BN>
-__device__ __forceinline__ void pipe_issue(const PipeSeg<BM, BN>& s, int kstep, char* stage, int wave) {
-  const uint32_t kbyte = (uint32_t)kstep * KB;
-#pragma unroll
-  for (int i = 0; i < BM * 8 / 256; ++i) {
-    lds_void_t* dst = (lds_void_t*)(stage + (i * 256 + wave * 64) * 16);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + kbyte, 0, 0, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < BN * 8 / 256; ++i) {
-    lds_void_t* dst = (lds_void_t*)(stage + BM * KB + (i * 256 + wave * 64) * 16);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + kbyte, 0, 0, 0);
-  }
-}
-
 // ---- fragment reads in inline asm -------------------------------------------------------------------------
 // hipcc's waitcnt pass treats every LDS-DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of any
 // ds_read it can see, which would drain the ring every K-step.  The fragment reads are therefore issued from asm
@@ -114,11 +99,25 @@ __device__ __forceinline__ void tile_mma_asm(uint32_t a_base, uint32_t b_base, c
       mma16<T>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
 }
 
+// Issue the (BM + BN) * 8 / 256 LDS-direct loads of pipeline stage `st` (K-steps of segment 0 first, then segment 1).
 template <int BM, int BN, int NBUF>
-__device__ __forceinline__ void pipe_issue_stage(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int s, int wave) {
-  char* stage = smem + (s % NBUF) * ((BM + BN) * KB);
-  if (s < s0.nk) pipe_issue<BM, BN>(s0, s, stage, wave);
-  else pipe_issue<BM, BN>(s1, s - s0.nk, stage, wave);
+__device__ __forceinline__ void pipe_issue_stage(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int st, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass cannot type-check LDS address-space casts / gfx950 builtins
+  char* stage = smem + (st % NBUF) * ((BM + BN) * KB);
+  const bool first = st < s0.nk;
+  const PipeSeg<BM, BN>& s = first ? s0 : s1;
+  const uint32_t kbyte = (uint32_t)(first ? st : st - s0.nk) * KB;
+#pragma unroll
+  for (int i = 0; i < BM * 8 / 256; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + (i * 256 + wave * 64) * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + kbyte, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < BN * 8 / 256; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + BM * KB + (i * 256 + wave * 64) * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + kbyte, 0, 0, 0);
+  }
+#endif
 }
 
 // acc += sum over segment 0 then segment 1 of A_tile . B_tile^T.   smem: NBUF * (BM + BN) * 128 bytes.

@@ -146,6 +146,9 @@ class _Workspace:
         return b
 
 
+_LDPAD = 64   # elements added to power-of-two leading dimensions of the big recurrent operands
+
+
 def _require_cuda(dev, what):
     if dev.type != "cuda":
         raise L.MvaeError(f"{what} runs on the MI355X only (no CPU fallback); move the module and inputs to cuda")
@@ -440,7 +443,8 @@ class MolDecoder(nn.Module):
         H, NL, o = g.hidden_size, g.num_layers, g.input_size
         G4 = 4 * H
         f32 = torch.float32
-        P = {"Wih": [None], "WihT": [None], "Whh": [], "WhhT": [], "bias": []}
+        ldw, ldwT = H + _LDPAD, G4 + _LDPAD       # leading dimensions kept off powers of two (L2 / MALL set conflicts)
+        P = {"Wih": [None], "WihT": [None], "Whh": [], "WhhT": [], "bias": [], "ldw": ldw, "ldwT": ldwT}
         with torch.no_grad():
             li = self.latent_input[0]
             P["WliT"] = ws.get("WliT", (o, _pad(o, 4)), f32, dev)
@@ -451,11 +455,11 @@ class MolDecoder(nn.Module):
                 b = ws.get(f"bias{l}", (G4,), f32, dev)
                 torch.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), out=b)
                 P["bias"].append(b)
-                w = ws.get(f"Whh{l}", (G4, H), dt, dev); wT = ws.get(f"WhhT{l}", (H, G4), dt, dev)
+                w = ws.get(f"Whh{l}", (G4, ldw), dt, dev); wT = ws.get(f"WhhT{l}", (H, ldwT), dt, dev)
                 ops.cast_transpose(getattr(g, f"weight_hh_l{l}"), G4, H, dst=w, dstT=wT)
                 P["Whh"].append(w); P["WhhT"].append(wT)
                 if l > 0:
-                    w = ws.get(f"Wih{l}", (G4, H), dt, dev); wT = ws.get(f"WihT{l}", (H, G4), dt, dev)
+                    w = ws.get(f"Wih{l}", (G4, ldw), dt, dev); wT = ws.get(f"WihT{l}", (H, ldwT), dt, dev)
                     ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), G4, H, dst=w, dstT=wT)
                     P["Wih"].append(w); P["WihT"].append(wT)
             om = self.decoded_mean.module[0]
@@ -493,15 +497,16 @@ class _DecoderFn(torch.autograd.Function):
         gx0 = ws.get("gx0", (B, G4), f32, dev)
         ops.gemm_nt(li, g.weight_ih_l0, gx0, B, G4, o, bias=P["bias"][0])
         # K7: 4-layer LSTM wavefront
-        hs = [ws.get(f"hs{l}", (Lq, B, H), dt, dev) for l in range(NL)]
+        ldh = H + _LDPAD
+        hs = [ws.get(f"hs{l}", (Lq, B, ldh), dt, dev) for l in range(NL)]
         hsT = [ws.get(f"hsT{l}", (H, ldT), dt, dev) for l in range(NL)]
         cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
         gates = [ws.get(f"gates{l}", (Lq, B, G4), dt, dev) for l in range(NL)]
-        ops.rnn_fwd(L.CELL_LSTM, dt, Lq, B, H, gx0, 0, P["Wih"], [H] * NL, P["Whh"], [H] * NL, [None] + P["bias"][1:],
-                    hs, H, hsT, ldT, cs, gates, tag="dec_lstm_fwd")
+        ops.rnn_fwd(L.CELL_LSTM, dt, Lq, B, H, gx0, 0, P["Wih"], [P["ldw"]] * NL, P["Whh"], [P["ldw"]] * NL, [None] + P["bias"][1:],
+                    hs, ldh, hsT, ldT, cs, gates, tag="dec_lstm_fwd")
         # K8: output head + softmax over the class axis
         logits = ws.get("logits", (TB, Cv), f32, dev)
-        ops.gemm_nt(hs[-1].view(TB, H), P["Wout"], logits, TB, Cv, H, bias=om.bias)
+        ops.gemm_nt(hs[-1].view(TB, ldh), P["Wout"], logits, TB, Cv, H, bias=om.bias)
         recon = torch.empty(B, Lq, Cv, dtype=f32, device=dev)
         ops.softmax_tb_fwd(logits, Cv, recon, B, Lq, Cv)
         ctx.mod, ctx.gen, ctx.z = mod, ws.generation, z
@@ -538,7 +543,8 @@ class _DecoderFn(torch.autograd.Function):
             off += p.numel()
         drecon = drecon.contiguous().float()
         W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
-        hs = [W(f"hs{l}", (Lq, B, H), dt) for l in range(NL)]
+        ldh, ldg = H + _LDPAD, G4 + _LDPAD
+        hs = [W(f"hs{l}", (Lq, B, ldh), dt) for l in range(NL)]
         hsT = [W(f"hsT{l}", (H, ldT), dt) for l in range(NL)]
         cs = [W(f"cs{l}", (Lq, B, H)) for l in range(NL)]
         gates = [W(f"gates{l}", (Lq, B, G4), dt) for l in range(NL)]
@@ -550,11 +556,11 @@ class _DecoderFn(torch.autograd.Function):
         dy = W("dy", (TB, H))
         ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
         # K7 backward
-        dG = [W(f"dG{l}", (Lq, B, G4), dt) for l in range(NL)]
+        dG = [W(f"dG{l}", (Lq, B, ldg), dt) for l in range(NL)]
         dGT = [W(f"dGT{l}", (G4, ldT), dt) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
-        ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dy, H, hs, H, cs, gates,
-                    dG, dGT, ldT, dstate, tag="dec_lstm_bwd")
+        ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [P["ldwT"]] * NL, P["WihT"], [P["ldwT"]] * NL, dy, H, hs, ldh, cs, gates,
+                    dG, dGT, ldT, dstate, ldg=ldg, tag="dec_lstm_bwd")
         with ops._Timed("dec_lstm_wgrad"):
             for l in range(NL):
                 if Lq > 1:
@@ -564,8 +570,8 @@ class _DecoderFn(torch.autograd.Function):
                 ops.rowsum(dGT[l], G4, TB, grads[f"gru.bias_ih_l{l}"])
                 grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
-        dgx0 = W("dgx0", (B, G4))
-        ops.timesum(dG[0], Lq, B, G4, dgx0)
+        dgx0 = W("dgx0", (B, ldg))           # pad columns of dG are zero, so the padded time sum is too
+        ops.timesum(dG[0], Lq, B, ldg, dgx0)
         li = W("li", (B, o))
         dgx0T, liT = W("dgx0T", (G4, Bp)), W("liT", (o, Bp))
         ops.cast_transpose(dgx0, B, G4, dstT=dgx0T); ops.cast_transpose(li, B, o, dstT=liT)

@@ -82,11 +82,11 @@ def gather_rows_tb(idx, table, out, B, Lq, nrows, W):
     check(L.load().mvae_gather_rows_tb(ptr(idx), B, Lq, nrows, ptr(table), W, ptr(out), stream_ptr()), "mvae_gather_rows_tb")
 
 
-def scatter_rows_tb(idx, d, dtable, B, Lq, nrows, W):
+def scatter_rows_tb(idx, d, dtable, B, Lq, nrows, W, ldd=None):
     lib = L.load()
     need = lib.mvae_scatter_rows_tb_workspace(B, Lq, nrows, W)
     ws = Scratch.get(need, d.device)
-    check(lib.mvae_scatter_rows_tb(dt_code(d.dtype), ptr(idx), B, Lq, nrows, ptr(d), W, W, ptr(dtable), ptr(ws), need,
+    check(lib.mvae_scatter_rows_tb(dt_code(d.dtype), ptr(idx), B, Lq, nrows, ptr(d), W if ldd is None else ldd, W, ptr(dtable), ptr(ws), need,
                                    stream_ptr()), "mvae_scatter_rows_tb")
 
 
@@ -193,7 +193,7 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
 
 
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dGT, ldT, dstate,
-            h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dGhT=None, dh0=None, tag=None):
+            ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dGhT=None, dh0=None, tag=None):
     d = L.RnnBwdDesc()
     NL = len(w_hhT)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
@@ -213,6 +213,7 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     if cs is not None:
         _fill(d.cs, cs)
     _fill(d.gates, gates); _fill(d.dG, dG)
+    d.ldg = ldg if ldg is not None else {"LSTM": 4, "GRU": 3}["LSTM" if cell == L.CELL_LSTM else "GRU"] * H
     if dGT is not None:
         _fill(d.dGT, dGT)
     d.ldT = ldT

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks at the decoder's shapes (B=512, H=1024, 4 layers, T steps): wavefront fwd / bwd steps and the
+weight-gradient GEMM.  Used for tuning and for the PMC profiles under profiles/.   python tests/bench_kernels.py [T] [B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import molecular_vae_amd as mv       # noqa: E402
+from molecular_vae_amd import ops, _lib as L   # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+which = sys.argv[3] if len(sys.argv) > 3 else "fwd,bwd,gemm"
+H, NL, PAD = 1024, 4, int(os.environ.get("LDPAD", 64))
+dev = torch.device("cuda")
+dt = torch.bfloat16
+G4 = 4 * H
+ldw, ldwT, ldh, ldg = H + PAD, G4 + PAD, H + PAD, G4 + PAD
+ldT = (T * B + 7) // 8 * 8 + 8
+g = torch.Generator(device="cuda").manual_seed(0)
+rnd = lambda *s: (torch.randn(*s, device=dev, generator=g) * 0.05)
+
+Wih = [None] + [rnd(G4, ldw).to(dt) for _ in range(NL - 1)]
+Whh = [rnd(G4, ldw).to(dt) for _ in range(NL)]
+WihT = [None] + [rnd(H, ldwT).to(dt) for _ in range(NL - 1)]
+WhhT = [rnd(H, ldwT).to(dt) for _ in range(NL)]
+bias = [None] + [rnd(G4) for _ in range(NL - 1)]
+gx0 = rnd(B, G4)
+hs = [torch.zeros(T, B, ldh, device=dev, dtype=dt) for _ in range(NL)]
+hsT = [torch.zeros(H, ldT, device=dev, dtype=dt) for _ in range(NL)]
+cs = [torch.zeros(T, B, H, device=dev) for _ in range(NL)]
+gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
+dG = [torch.zeros(T, B, ldg, device=dev, dtype=dt) for _ in range(NL)]
+dGT = [torch.zeros(G4, ldT, device=dev, dtype=dt) for _ in range(NL)]
+dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
+dy = rnd(T * B, H)
+
+
+def fwd():
+    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, 0, Wih, [ldw] * NL, Whh, [ldw] * NL, bias, hs, ldh, hsT, ldT, cs, gates)
+
+
+def bwd():
+    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, WhhT, [ldwT] * NL, WihT, [ldwT] * NL, dy, H, hs, ldh, cs, gates, dG, dGT, ldT, dstate, ldg=ldg)
+
+
+dW = torch.zeros(G4, H, device=dev)
+
+
+def gemm():
+    ops.gemm_nt(dGT[1], hsT[0], dW, G4, H, T * B, lda=ldT, ldb=ldT)
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+nl = T + NL - 1
+per_t = 2 * B * G4 * (H + 3 * 2 * H)
+if "fwd" in which:
+    ms = timeit(fwd)
+    print(f"fwd : {ms:.3f} ms  {1e3 * ms / nl:.1f} us/launch  {per_t * T / ms / 1e9:.1f} TFLOP/s")
+if "bwd" in which:
+    ms = timeit(bwd)
+    print(f"bwd : {ms:.3f} ms  {1e3 * ms / nl:.1f} us/launch  {per_t * T / ms / 1e9:.1f} TFLOP/s")
+if "gemm" in which:
+    ms = timeit(gemm)
+    print(f"gemm: {ms:.3f} ms  M={G4} N={H} K={T * B}  {2 * G4 * H * T * B / ms / 1e9:.1f} TFLOP/s")

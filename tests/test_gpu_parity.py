@@ -1,0 +1,249 @@
+"""GPU parity tests (pytest -m gpu): the HIP path through the C ABI vs the CPU oracle on the same seeded inputs, the golden
+fixtures generated from the reference, and size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (north_star: 1e-4 relative on the ELBO and the encoder mu / log sigma^2):
+  f32 path   loss, mu, logvar, recon <= 1e-5 rel (well inside 1e-4); every parameter gradient <= 2e-4 rel (max-norm)
+  bf16 path  loss <= 1e-4 rel; mu / logvar identical to the f32 path (the encoder is always f32); recon <= 5e-3;
+             parameter gradients <= 5e-2 rel (bf16 storage of decoder activations, fp32 accumulate)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gpu_helpers as gh            # noqa: E402
+from gpu_helpers import O, ip, mv, rel   # noqa: E402
+from molecular_vae_amd import ops, _lib as L   # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dev = torch.device("cuda")
+
+
+def t(a, dt=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(np.float32)).to(dev).to(dt)
+
+
+def test_native_library_is_the_one_running():
+    lib = L.load()
+    assert lib.mvae_abi_version() == 1
+    assert os.path.samefile(L.LIB_PATH, os.path.join(ROOT, "molecular-vae_amd", "libmvae_hip.so"))
+    assert any("libmvae_hip.so" in line for line in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 5e-6), (torch.bfloat16, 1e-6)])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 128, 256), (300, 200, 96), (35, 1024, 2048), (17, 9, 40), (1, 5, 8),
+                                   (4096, 1024, 1024), (288, 72, 2880), (300, 200, 512), (130, 70, 4096), (512, 4096, 296)])
+def test_gemm_nt(dt, tol, shape):
+    """All tile variants: 64/128 tiles, split-K, ragged edges, register-staged and LDS-direct pipelined main loops.
+    Inputs are pre-rounded to the storage type, so the check isolates the kernel (fp32 accumulate)."""
+    M, N, K = shape
+    rs = np.random.RandomState(M * 7 + N * 3 + K)
+    A, B = t(rs.standard_normal((M, K)), dt), t(rs.standard_normal((N, K)), dt)
+    bias = t(rs.standard_normal(N))
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_nt(A, B, out, M, N, K, bias=bias, act=L.ACT_SELU)
+    ref = O.selu(A.double().cpu().numpy() @ B.double().cpu().numpy().T + bias.double().cpu().numpy())
+    assert rel(out.cpu().numpy(), ref) < tol
+
+
+def _lstm_case(dt, T, B, H, NL, In, seed=2):
+    rs = np.random.RandomState(seed)
+    G4 = 4 * H
+    p = {}
+    for l in range(NL):
+        inp = In if l == 0 else H
+        p[f"g.weight_ih_l{l}"] = rs.uniform(-0.4, 0.4, (G4, inp)); p[f"g.weight_hh_l{l}"] = rs.uniform(-0.4, 0.4, (G4, H))
+        p[f"g.bias_ih_l{l}"] = rs.uniform(-0.2, 0.2, G4); p[f"g.bias_hh_l{l}"] = rs.uniform(-0.2, 0.2, G4)
+    if dt == torch.bfloat16:
+        for k in p:
+            if "weight" in k:
+                p[k] = torch.from_numpy(p[k]).bfloat16().double().numpy()
+    x = rs.standard_normal((T, B, In))
+    y, caches = O.lstm_fwd(x, p, "g", NL)
+    dy = rs.standard_normal((T, B, H))
+    grads = {}
+    dx = O.lstm_bwd(dy, caches, grads, "g")
+    gx0 = t((x.reshape(T * B, In) @ p["g.weight_ih_l0"].T + p["g.bias_ih_l0"] + p["g.bias_hh_l0"]).reshape(T, B, G4))
+    ldT = (T * B + 7) // 8 * 8 + 8
+    ldh, ldg = H + 8, G4 + 8
+    hs = [torch.zeros(T, B, ldh, device=dev, dtype=dt) for _ in range(NL)]
+    hsT = [torch.zeros(H, ldT, device=dev, dtype=dt) for _ in range(NL)]
+    cs = [torch.zeros(T, B, H, device=dev) for _ in range(NL)]
+    gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
+    w_ih = [None] + [t(p[f"g.weight_ih_l{l}"], dt) for l in range(1, NL)]
+    w_hh = [t(p[f"g.weight_hh_l{l}"], dt) for l in range(NL)]
+    bias = [None] + [t(p[f"g.bias_ih_l{l}"] + p[f"g.bias_hh_l{l}"]) for l in range(1, NL)]
+    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, B * G4, w_ih, [H] * NL, w_hh, [H] * NL, bias, hs, ldh, hsT, ldT, cs, gates)
+    w_hhT = [t(p[f"g.weight_hh_l{l}"].T, dt) for l in range(NL)]
+    w_ihT = [None] + [t(p[f"g.weight_ih_l{l}"].T, dt) for l in range(1, NL)]
+    dG = [torch.zeros(T, B, ldg, device=dev, dtype=dt) for _ in range(NL)]
+    dGT = [torch.zeros(G4, ldT, device=dev, dtype=dt) for _ in range(NL)]
+    dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
+    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, w_hhT, [G4] * NL, w_ihT, [G4] * NL, t(dy), H, hs, ldh, cs, gates, dG, dGT, ldT, dstate, ldg=ldg)
+    torch.cuda.synchronize()
+    errs = {}
+    for l in range(NL):
+        errs[f"h{l}"] = rel(hs[l][:, :, :H].float().cpu().numpy(), caches[l][1])
+        errs[f"c{l}"] = rel(cs[l].cpu().numpy(), caches[l][2])
+        errs[f"hT{l}"] = rel(hsT[l][:, :T * B].float().cpu().numpy(), caches[l][1].reshape(T * B, H).T)
+        assert float(hs[l][:, :, H:].abs().sum()) == 0.0          # pad columns stay zero
+        dwhh = torch.zeros(G4, H, device=dev)
+        ops.gemm_nt(dGT[l][:, B:], hsT[l], dwhh, G4, H, T * B - B, lda=ldT, ldb=ldT)
+        errs[f"dWhh{l}"] = rel(dwhh.cpu().numpy(), grads[f"g.weight_hh_l{l}"])
+        db = torch.zeros(G4, device=dev)
+        ops.rowsum(dGT[l], G4, T * B, db)
+        errs[f"db{l}"] = rel(db.cpu().numpy(), grads[f"g.bias_ih_l{l}"])
+        if l > 0:
+            dwih = torch.zeros(G4, H, device=dev)
+            ops.gemm_nt(dGT[l], hsT[l - 1], dwih, G4, H, T * B, lda=ldT, ldb=ldT)
+            errs[f"dWih{l}"] = rel(dwih.cpu().numpy(), grads[f"g.weight_ih_l{l}"])
+        assert torch.equal(dGT[l][:, :T * B], dG[l][:, :, :G4].reshape(T * B, G4).t())
+    dx_h = dG[0][:, :, :G4].float().cpu().numpy().reshape(T * B, G4) @ p["g.weight_ih_l0"]
+    errs["dx"] = rel(dx_h.reshape(T, B, In), dx)
+    return errs
+
+
+@pytest.mark.parametrize("case", [
+    (torch.float32, 7, 5, 32, 2, 16, 2e-5),       # tiny, generic register-staged path
+    (torch.bfloat16, 7, 5, 32, 2, 16, 3e-2),
+    (torch.float32, 5, 70, 72, 3, 8, 2e-5),       # encoder-like H=72 (ragged K), 3 layers
+    (torch.bfloat16, 6, 130, 128, 3, 8, 3e-2),    # LDS-direct pipelined path, ragged rows
+    (torch.float32, 4, 200, 64, 2, 8, 2e-5),      # pipelined path, f32 MFMA
+    (torch.bfloat16, 3, 256, 192, 4, 8, 3e-2),    # 4 layers, 128-row tiles
+    (torch.bfloat16, 1, 9, 64, 2, 8, 3e-2),       # T = 1 edge case
+])
+def test_lstm_wavefront_fwd_bwd_vs_oracle(case):
+    dt, T, B, H, NL, In, tol = case
+    errs = _lstm_case(dt, T, B, H, NL, In)
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, bad
+
+
+def test_small_ops_vs_oracle():
+    rs = np.random.RandomState(3)
+    B, Lq, C, o = 5, 11, 12, 16
+    logits = rs.standard_normal((Lq * B, C)) * 2
+    recon = torch.empty(B, Lq, C, device=dev)
+    ops.softmax_tb_fwd(t(logits), C, recon, B, Lq, C)
+    e = np.exp(logits - logits.max(1, keepdims=True)); pr = (e / e.sum(1, keepdims=True)).reshape(Lq, B, C).transpose(1, 0, 2)
+    assert rel(recon.cpu().numpy(), pr) < 1e-6
+    idx = rs.randint(0, C, (B, Lq)); ohe = O.one_hot(idx, C)
+    mu = rs.standard_normal((B, o)); lv = rs.standard_normal((B, o))
+    out = torch.empty(3, device=dev)
+    ops.bce_kl_loss_fwd(recon, t(ohe), t(mu), t(lv), Lq, out)
+    ref = O.bce_kl_loss(pr, ohe, mu, lv, Lq)
+    assert rel(out.cpu().numpy(), np.array(ref)) < 1e-6
+    drecon = torch.empty_like(recon); dmu = torch.empty(B, o, device=dev); dlv = torch.empty(B, o, device=dev)
+    ops.bce_kl_loss_bwd(recon, t(ohe), t(mu), t(lv), Lq, None, drecon, dmu, dlv)
+    r = O.bce_kl_loss_bwd(pr, ohe, mu, lv, Lq)
+    assert rel(drecon.cpu().numpy(), r[0]) < 1e-5 and rel(dmu.cpu().numpy(), r[1]) < 1e-6 and rel(dlv.cpu().numpy(), r[2]) < 1e-6
+    # BCELoss edge cases: p exactly 0 / 1 hit the -100 log clamp and the 1e-12 denominator clamp
+    pe = torch.tensor([0.0, 1.0, 1.0, 0.0, 0.5], device=dev); te = torch.tensor([1.0, 0.0, 1.0, 0.0, 1.0], device=dev)
+    ops.bce_kl_loss_fwd(pe, te, t(mu), t(lv), 1.0, out)
+    assert abs(float(out[1]) - (100 + 100 + 0 + 0 + np.log(2)) / 5) < 1e-4
+    # adam + clip
+    n = 200000
+    p0 = rs.standard_normal(n); g0 = rs.standard_normal(n) * 0.05
+    P = {"w": p0.copy()}; st = {}
+    tp, tg, tm, tv = t(p0), t(g0), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    partial = torch.zeros((n + 65535) // 65536, device=dev); norm = torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        gc, total = O.clip_grad_norm({"w": g0}, 3.0)
+        P = O.adam_step(P, gc, st, lr=8e-4)
+        ops.sumsq(tg, partial)
+        ops.clip_adam(tp, tg, tm, tv, partial, 1.0, 3.0, 8e-4, 0.9, 0.999, 1e-8, step, norm)
+    assert rel(tp.cpu().numpy(), P["w"]) < 1e-6 and abs(float(norm) - total) < 1e-4 * total
+
+
+def _model_check(dims, params, idx, eps, dtype, tol_loss, tol_lat, tol_recon, tol_grad, golden_loss=None):
+    p64 = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    ref = O.molvae_loss_and_grads(p64, idx, np.asarray(eps, np.float64), max_len=dims["i"], num_lstm=dims["n_enc"], num_gru=dims["n_dec"])
+    enc, dec = gh.build_modules(dims, params, dtype)
+    out = gh.run_hip(enc, dec, idx, eps, dims["i"])
+    assert abs(out["loss"] - ref["loss"]) < tol_loss * abs(ref["loss"])
+    if golden_loss is not None:          # fixture generated from the reference itself
+        assert abs(out["loss"] - golden_loss) < tol_loss * abs(golden_loss)
+    assert rel(out["mu"], ref["mu"]) < tol_lat and rel(out["logvar"], ref["logvar"]) < tol_lat
+    assert rel(out["recon"], ref["recon"]) < tol_recon
+    rep = gh.grad_report(out["grads"], ref["grads"])
+    bad = {k: v for k, v in rep.items() if v > tol_grad}
+    assert not bad, bad
+    return out, ref
+
+
+def test_g1_small_model_f32_and_bf16(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_small.npz"))
+    params = gh.g1_dims_params(np.float32)
+    out, _ = _model_check(gh.G1, params, g["idx"], g["eps"], torch.float32, 1e-5, 1e-5, 1e-5, 2e-4, float(g["loss"]))
+    assert rel(out["mu"], g["mu"]) < 1e-5 and rel(out["logvar"], g["logvar"]) < 1e-5 and rel(out["recon"], g["recon"]) < 1e-5
+    for k in [f for f in g.files if f.startswith("grad.")]:
+        assert rel(out["grads"][k[5:]], g[k]) < 2e-4, k
+    _model_check(gh.G1, params, g["idx"], g["eps"], torch.bfloat16, 1e-4, 1e-5, 5e-3, 5e-2, float(g["loss"]))
+
+
+def test_g2_full_dims_f32_and_bf16(golden_dir):
+    """Full model (L=120, C=35, o=292, 4x LSTM-1024), B=4, against the oracle AND the reference-generated fixture."""
+    g = np.load(os.path.join(golden_dir, "g2_full.npz"))
+    params = ip.init_params(ip.molvae_shapes(), 202, 1.5, np.float32)
+    out, _ = _model_check(gh.FULL, params, g["idx"], g["eps"], torch.float32, 1e-5, 1e-5, 1e-5, 5e-4, float(g["loss"]))
+    assert rel(out["mu"], g["mu"]) < 1e-5 and rel(out["logvar"], g["logvar"]) < 1e-5
+    assert rel(out["recon"][:, ::17, :], g["recon_rows"]) < 1e-5
+    for k, gr in out["grads"].items():
+        assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - float(g["gnorm." + k])) < 5e-4 * float(g["gnorm." + k]) + 1e-12, k
+    _model_check(gh.FULL, params, g["idx"], g["eps"], torch.bfloat16, 1e-4, 1e-5, 5e-3, 5e-2, float(g["loss"]))
+
+
+def test_g4_clip_adam_trajectory(golden_dir):
+    """5 steps of train.py:95-104 (clip 3.0 + Adam 8e-4) with FusedAdam reproduce the reference's loss trajectory."""
+    g = np.load(os.path.join(golden_dir, "g4_traj.npz")); g1 = np.load(os.path.join(golden_dir, "g1_small.npz"))
+    enc, dec = gh.build_modules(gh.G1, gh.g1_dims_params(np.float32), torch.float32)
+    opt = mv.FusedAdam(list(enc.parameters()) + list(dec.parameters()), lr=0.0008, max_grad_norm=3.0)
+    idx = torch.from_numpy(g1["idx"]).to(dev)
+    ohe = torch.nn.functional.one_hot(idx, gh.G1["c"]).float()
+    for step in range(5):
+        opt.zero_grad(set_to_none=True)
+        z, mu, logvar = enc(idx, t(g["eps"][step]))
+        loss = mv.bce_kl_loss(dec(z), ohe, mu, logvar, gh.G1["i"])
+        loss.backward()
+        opt.step()
+        assert abs(float(loss) - g["losses"][step]) < 2e-4 * g["losses"][step], (step, float(loss), g["losses"][step])
+        assert abs(float(opt.last_grad_norm) - g["gnorms"][step]) < 1e-3 * g["gnorms"][step]
+    for pre, m in (("encoder.", enc), ("decoder.", dec)):
+        for k, v in m.named_parameters():
+            a = v.detach().cpu().numpy().astype(np.float64)
+            assert abs(np.sqrt((a ** 2).sum()) - float(g["fnorm." + pre + k])) < 1e-4 * (1 + float(g["fnorm." + pre + k])), k
+
+
+def test_full_size_properties_batch512():
+    """BASELINE.json configs[1] size (B=512, L=120, C=35): properties that need no oracle run.
+       * recon rows are probability vectors; * the fused loss equals a plain torch evaluation of train.py:31-38 on the same
+       recon; * run-to-run bitwise determinism of loss and gradients; * batch-row independence: the first 64 molecules give the
+       same mu as a B=64 run."""
+    torch.manual_seed(42)
+    model = mv.MolecularVAE().to(dev)
+    gen = torch.Generator().manual_seed(1234)
+    idx = torch.randint(0, 35, (512, 120), generator=gen).to(dev)
+    eps = (1e-2 * torch.randn(512, 292, generator=gen)).to(dev)
+    ohe = torch.nn.functional.one_hot(idx, 35).float()
+
+    def run(ix, ep, oh):
+        model.zero_grad(set_to_none=True)
+        recon, mu, logvar = model(ix, ep)
+        loss = mv.bce_kl_loss(recon, oh, mu, logvar, 120)
+        loss.backward()
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters()))
+        return recon.detach(), mu.detach(), logvar.detach(), loss.detach(), gn
+
+    recon, mu, logvar, loss, gn = run(idx, eps, ohe)
+    assert torch.allclose(recon.sum(-1), torch.ones(512, 120, device=dev), atol=1e-5) and float(recon.min()) >= 0
+    bce = torch.nn.functional.binary_cross_entropy(recon.reshape(-1), ohe.reshape(-1))
+    ref_loss = 120 * bce - 0.5 * torch.mean(1. + mu - logvar ** 2 - torch.exp(mu))
+    assert abs(float(loss) - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+    recon2, mu2, logvar2, loss2, gn2 = run(idx, eps, ohe)
+    assert torch.equal(recon, recon2) and torch.equal(mu, mu2) and float(loss) == float(loss2) and float(gn) == float(gn2)
+    _, mu64, _, _, _ = run(idx[:64], eps[:64], ohe[:64])
+    assert torch.allclose(mu64, mu[:64], rtol=1e-5, atol=1e-6)
+    assert np.isfinite(float(gn)) and float(gn) > 0
