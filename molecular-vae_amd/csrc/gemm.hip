@@ -117,7 +117,8 @@ Plan make_plan(int M, int N, int K, int dtype) {
   pl.tiles_m = (M + pl.bm - 1) / pl.bm;
   pl.tiles_n = (N + pl.bm - 1) / pl.bm;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
-  const long ksteps = (K + ke - 1) / ke;
+  long ksteps = (K + ke - 1) / ke;
+  if (ksteps < 1) ksteps = 1;                 // K == 0: one empty pass, the epilogue still writes bias / zeros
   int splits = 1;
   if (tiles < 128 && ksteps >= 16) {
     splits = (int)((256 + tiles - 1) / tiles);
