@@ -62,6 +62,15 @@ int mvae_gemm_nt(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
                  void* C, int64_t ldc, int dtype_c, const float* bias, int act, int accumulate,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* C[M,N] = act( A^T . B + bias[N] ) with A [K, lda] and B [K, ldb] both K-major (row = k): the weight-gradient contraction
+ * dW = dG^T . X reading dG [T*B, 4H] and X [T*B, H] as the recurrent kernels wrote them (hardware-transposed LDS reads, no
+ * transposed copies).  bf16 operands only (MVAE_ERR_UNSUPPORTED otherwise: f32 callers use mvae_cast_transpose + mvae_gemm_nt).
+ * lda, ldb multiples of 8; rows k >= K are never read.  Replaces autograd's weight-gradient GEMMs of models.py:128,164,157. */
+size_t mvae_gemm_tn_workspace(int M, int N, int K, int dtype_ab);
+int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                 void* C, int64_t ldc, int dtype_c, const float* bias, int act, int accumulate,
+                 void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Data movement helpers.
  */
@@ -96,10 +105,10 @@ size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W);
  * Repeat), or both.  bias[l] (fp32 [G*H]) is added for layers whose input is a real sequence.
  *
  * Saved for backward (all caller-allocated):
- *   hs[l]    [T][B][ldh]   dtype   layer outputs h_t          (hs[layers-1] is the stack output)
- *   hsT[l]   [H][ldT]      dtype   the same transposed, column t*B+b  (may be NULL: not written)
- *   cs[l]    [T][B][H]     fp32    cell states (LSTM only)
- *   gates[l] [T][B][G*H]   dtype   post-activation gates i,f,g,o (LSTM) / r,z,n,(W_hn h + b_hn) (GRU)
+ *   hs[l]     [T][B][ldh]   dtype   layer outputs h_t          (hs[layers-1] is the stack output)
+ *   cs[l]     [T][B][H]     dtype   cell states as the backward pass reads them (LSTM only)
+ *   gates[l]  [T][B][G*H]   dtype   post-activation gates i,f,g,o (LSTM) / r,z,n,(W_hn h + b_hn) (GRU)
+ *   cstate[l] [2][B][H]     fp32    scratch: the recurrent cell state itself stays fp32 (ping-pong over t)
  * lengths (GRU path): per-sequence valid length, sorted descending (pack_sequence semantics: a finished
  * sequence keeps its last state and emits zeros); NULL = all T.
  */
@@ -113,9 +122,9 @@ typedef struct {
   const void* h0[MVAE_MAX_LAYERS]; int64_t ldh0;                         /* optional initial hidden state [B, ldh0] dtype (NULL = zeros) */
   const int32_t* lengths;
   void* hs[MVAE_MAX_LAYERS]; int64_t ldh;
-  void* hsT[MVAE_MAX_LAYERS]; int64_t ldT;
-  float* cs[MVAE_MAX_LAYERS];
+  void* cs[MVAE_MAX_LAYERS];
   void* gates[MVAE_MAX_LAYERS];
+  float* cstate[MVAE_MAX_LAYERS];
 } mvae_rnn_fwd_desc;
 
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
@@ -126,10 +135,8 @@ int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
  *   w_hhT[l] [H, G*H], w_ihT[l] [in, G*H]: TRANSPOSED weights (K-contiguous for this contraction).
  *   dy       [T][B][H] fp32 gradient w.r.t. the stack output (row stride dy_ld).
  *   dG[l]    [T][B][ldg]  dtype  (out)  pre-activation gradients (G*H valid columns); dG[0] is also the gradient of add0.
- *   dGT[l]   [G*H][ldT]  dtype  (out, may be NULL)  transposed copy feeding the weight-gradient GEMMs
- *                               (GRU: dGT holds the W_ih-side gradient rows [r,z,n]; dGhT the W_hh-side).
- *   dcs      2*layers fp32 [B,H] scratch (ping-pong dc), dh_carry: GRU scratch.
- * Weight / bias / input gradients are then plain mvae_gemm_nt / mvae_rowsum calls on dGT, hsT.
+ *   dstate[l] [2][B][H] fp32 scratch (ping-pong dc).
+ * Weight / bias / input gradients are then mvae_gemm_tn(dG[l], hs[l-1] / hs[l] shifted by one step) and mvae_colsum_t(dG[l]).
  */
 typedef struct {
   int cell, dtype, layers, T, B, H;
@@ -140,11 +147,10 @@ typedef struct {
   const float* dh_last[MVAE_MAX_LAYERS];                                  /* optional fp32 [B,H] gradient w.r.t. the final hidden state */
   const void* hs[MVAE_MAX_LAYERS]; int64_t ldh;
   const void* h0[MVAE_MAX_LAYERS]; int64_t ldh0;
-  const float* cs[MVAE_MAX_LAYERS];
+  const void* cs[MVAE_MAX_LAYERS];
   const void* gates[MVAE_MAX_LAYERS];
   void* dG[MVAE_MAX_LAYERS]; int64_t ldg;                                  /* row stride of dG (>= G*H; pad it off powers of two) */
-  void* dGT[MVAE_MAX_LAYERS]; int64_t ldT;
-  void* dGh[MVAE_MAX_LAYERS]; void* dGhT[MVAE_MAX_LAYERS];               /* GRU only */
+  void* dGh[MVAE_MAX_LAYERS];                                              /* GRU only: W_hh-side gradient rows */
   float* dstate[MVAE_MAX_LAYERS];                                         /* fp32 [2][B][H] ping-pong: LSTM dc, GRU dh carry */
   float* dh0[MVAE_MAX_LAYERS];                                            /* optional out: gradient w.r.t. h0 (GRU decoder_lat path) */
 } mvae_rnn_bwd_desc;
@@ -158,6 +164,9 @@ int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void
 /* out[n] = sum_m X[m, n] (fp32 in/out, deterministic two-stage): bias gradients of the dense / conv layers. */
 size_t mvae_colsum_workspace(int M, int N);
 int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream);
+/* same for X of `dtype` read in 16-byte vectors (ldx multiple of 8, X 16-byte aligned): bias gradients from dG [T*B, G*H]. */
+size_t mvae_colsum_t_workspace(int M, int N);
+int mvae_colsum_t(int dtype, int M, int N, const void* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Conv1d(k) + bias + SELU, valid, stride 1 (K3; models.py:71-77 ConvSELU, :118-120, :129-131) as an
@@ -194,7 +203,7 @@ int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const flo
  * Output head (K8; models.py:157 Linear + nn.Softmax() over the class axis of the [B*L, C] view,
  * models.py:43-50).  logits [(t*B+b), ldl] fp32 -> recon [B, L, C] fp32 probabilities.
  * Backward: dlogits = p * (drecon - sum_c drecon*p), written in dtype as dl [(t*B+b), ldd] (zero padded
- * columns C..ldd-1) and transposed dlT [Cpad][ldT] (column t*B+b).
+ * columns C..ldd-1) and, when dlT != NULL, transposed dlT [C][ldT] (column t*B+b).
  */
 int mvae_softmax_tb_fwd(int B, int L, int C, const float* logits, int64_t ldl, float* recon, void* stream);
 int mvae_softmax_tb_bwd(int dtype, int B, int L, int C, const float* recon, const float* drecon,

@@ -27,9 +27,9 @@ class RnnFwdDesc(C.Structure):
                 ("h0", _vp * MAX_LAYERS), ("ldh0", _i64),
                 ("lengths", _vp),
                 ("hs", _vp * MAX_LAYERS), ("ldh", _i64),
-                ("hsT", _vp * MAX_LAYERS), ("ldT", _i64),
                 ("cs", _vp * MAX_LAYERS),
-                ("gates", _vp * MAX_LAYERS)]
+                ("gates", _vp * MAX_LAYERS),
+                ("cstate", _vp * MAX_LAYERS)]
 
 
 class RnnBwdDesc(C.Structure):
@@ -44,8 +44,7 @@ class RnnBwdDesc(C.Structure):
                 ("cs", _vp * MAX_LAYERS),
                 ("gates", _vp * MAX_LAYERS),
                 ("dG", _vp * MAX_LAYERS), ("ldg", _i64),
-                ("dGT", _vp * MAX_LAYERS), ("ldT", _i64),
-                ("dGh", _vp * MAX_LAYERS), ("dGhT", _vp * MAX_LAYERS),
+                ("dGh", _vp * MAX_LAYERS),
                 ("dstate", _vp * MAX_LAYERS),
                 ("dh0", _vp * MAX_LAYERS)]
 
@@ -56,6 +55,8 @@ SIGNATURES = {
     "mvae_status_string": (C.c_char_p, [_i]),
     "mvae_gemm_nt_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_gemm_nt": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "mvae_gemm_tn_workspace": (_sz, [_i, _i, _i, _i]),
+    "mvae_gemm_tn": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "mvae_cast_transpose": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "mvae_permute021": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "mvae_gather_rows_tb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -67,6 +68,8 @@ SIGNATURES = {
     "mvae_timesum": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "mvae_colsum_workspace": (_sz, [_i, _i]),
     "mvae_colsum": (_i, [_i, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "mvae_colsum_t_workspace": (_sz, [_i, _i]),
+    "mvae_colsum_t": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
     "mvae_conv1d_selu_fwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "mvae_conv1d_selu_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "mvae_conv1d_selu_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),

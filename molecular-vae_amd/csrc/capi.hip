@@ -26,6 +26,14 @@ int mvae_gemm_nt(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
   return launch_gemm_nt(dtype_ab, M, N, K, A, lda, B, ldb, C, ldc, dtype_c, bias, act, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
+size_t mvae_gemm_tn_workspace(int M, int N, int K, int dtype_ab) { return dtype_ab == MVAE_BF16 ? gemm_tn_workspace_bytes(M, N, K) : 0; }
+
+int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                 int dtype_c, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (dtype_ab != MVAE_BF16) return MVAE_ERR_UNSUPPORTED;   // f32 callers transpose explicitly (mvae_cast_transpose) and use mvae_gemm_nt
+  return launch_gemm_tn_bf16(M, N, K, A, lda, B, ldb, C, ldc, dtype_c, bias, act, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) { return rnn_fwd_impl(d, (hipStream_t)stream); }
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
 

@@ -171,6 +171,52 @@ int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, 
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
+// out[n] = sum_m X[m, n] for X of type T read as 16-byte vectors: thread = 8 columns x (every 8th row of its chunk);
+// block = 32 column groups (256 columns) x 8 row slots; fixed-order LDS + chunk reduction.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_t_stage1_kernel(int M, int N, const T* X, long ldx, int rows_per_chunk, float* partial) {
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, rs = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cg * 8;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    const int n = (N - c0 < 8) ? (N - c0) : 8;
+    for (int m = r0 + rs; m < r1; m += 8) {
+      float v[8];
+      const T* p = X + (long)m * ldx + c0;
+      if (n == 8) {
+        if constexpr (sizeof(T) == 2) {
+          const uint4 u = *reinterpret_cast<const uint4*>(p);
+          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
+        } else {
+          const float4 x0 = *reinterpret_cast<const float4*>(p), x1 = *reinterpret_cast<const float4*>(p + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (e < n) ? TT<T>::ld(p + e) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rs][cg * 8 + e] = a[e];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][threadIdx.x];
+    partial[(long)blockIdx.y * N + c] = v;
+  }
+}
+static int colsum_t_chunks(int M) { int c = (M + 255) / 256; if (c > 240) c = 240; if (c < 1) c = 1; return c; }
+
 // out[r] (+)= sum_c X[r, c]: one wave per row, 16-byte loads when the row is 16-byte aligned
 template <typename T> __device__ __forceinline__ float sum_chunk16(const uint4& v);
 template <> __device__ __forceinline__ float sum_chunk16<float>(const uint4& v) {
@@ -412,6 +458,22 @@ int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void
   if (dtype == MVAE_F32) hipLaunchKernelGGL((timesum_kernel<float>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const float*)X, out);
   else if (dtype == MVAE_BF16) hipLaunchKernelGGL((timesum_kernel<bf16_t>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
   else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+size_t mvae_colsum_t_workspace(int M, int N) { return (size_t)colsum_t_chunks(M) * N * sizeof(float); }
+int mvae_colsum_t(int dtype, int M, int N, const void* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!X || !out || M < 0 || N < 1) return MVAE_ERR_INVALID;
+  if ((ldx % 8) || (reinterpret_cast<uintptr_t>(X) & 15)) return MVAE_ERR_INVALID;
+  if (!ws || ws_bytes < mvae_colsum_t_workspace(M, N)) return MVAE_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = colsum_t_chunks(M);
+  const int rpc = (M + chunks - 1) / chunks;
+  dim3 grid((N + 255) / 256, chunks);
+  if (dtype == MVAE_F32) hipLaunchKernelGGL((colsum_t_stage1_kernel<float>), grid, dim3(256), 0, st, M, N, (const float*)X, ldx, rpc, (float*)ws);
+  else if (dtype == MVAE_BF16) hipLaunchKernelGGL((colsum_t_stage1_kernel<bf16_t>), grid, dim3(256), 0, st, M, N, (const bf16_t*)X, ldx, rpc, (float*)ws);
+  else return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(grid_for(N)), dim3(256), 0, st, (const float*)ws, chunks, (long)N, out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

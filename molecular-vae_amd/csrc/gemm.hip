@@ -106,6 +106,50 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
   }
 }
 
+// C[M,N] = A^T . B with A [K][lda], B [K][ldb] (bf16, K-major): the weight-gradient contraction (see tile_pipe.hpp, TN form).
+template <int NBUF>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int split = blockIdx.y;
+  const long kbeg = (long)split * p.kper;
+  const long kend = (kbeg + p.kper < (long)p.K) ? (kbeg + p.kper) : (long)p.K;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PipeSegTN s;
+  pipe_seg_tn_init(s, reinterpret_cast<const bf16_t*>(p.A) + kbeg * p.lda, p.lda, m0, reinterpret_cast<const bf16_t*>(p.B) + kbeg * p.ldb,
+                   p.ldb, n0, (int)(kend - kbeg), tid);
+  tile_gemm_pipe_tn<NBUF>(smem, s, wm, wn, acc, tid);
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + lr;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + lq * 4 + r;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splits > 1) {
+          p.partial[((long)split * p.M + row) * p.N + col] = v;
+        } else {
+          if (p.bias) v += p.bias[col];
+          if (p.act == MVAE_ACT_SELU) v = selu_f(v);
+          store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
+        }
+      }
+    }
+}
+
 namespace {
 struct Plan { int bm, tiles_m, tiles_n, splits; long kper; };
 
@@ -180,6 +224,70 @@ int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, cons
     else { if (pipe) MVAE_GEMM_LAUNCH(float, 64, true); else MVAE_GEMM_LAUNCH(float, 64, false); }
   }
 #undef MVAE_GEMM_LAUNCH
+  MVAE_CHECK_HIP(hipGetLastError());
+  if (pl.splits > 1) {
+    long n = (long)M * N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), block, 0, st, p);
+    MVAE_CHECK_HIP(hipGetLastError());
+  }
+  return MVAE_OK;
+}
+
+// ---- TN (bf16): plan = 128x128 tiles, K-steps of 64 rows, split-K when the output alone cannot fill the chip
+namespace {
+Plan make_plan_tn(int M, int N, int K) {
+  Plan pl;
+  pl.bm = 128;
+  pl.tiles_m = (M + 127) / 128; pl.tiles_n = (N + 127) / 128;
+  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  long ksteps = (K + 63) / 64;
+  if (ksteps < 1) ksteps = 1;
+  int splits = 1;
+  if (tiles < 192 && ksteps >= 16) {
+    splits = (int)((256 + tiles - 1) / tiles);
+    const long maxs = ksteps / 8;
+    if (splits > maxs) splits = (int)maxs;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  const long per = (ksteps + splits - 1) / splits;
+  pl.splits = (int)((ksteps + per - 1) / per);
+  pl.kper = per * 64;
+  return pl;
+}
+}  // namespace
+
+size_t gemm_tn_workspace_bytes(int M, int N, int K) {
+  Plan pl = make_plan_tn(M, N, K);
+  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+}
+
+int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
+                        const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (M <= 0 || N <= 0) return MVAE_OK;
+  if (K < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
+  if (c_dtype != MVAE_F32 && c_dtype != MVAE_BF16) return MVAE_ERR_INVALID;
+  if (accumulate && c_dtype != MVAE_F32) return MVAE_ERR_INVALID;
+  if ((lda % 8) || (ldb % 8) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15)) return MVAE_ERR_INVALID;
+  if ((long)K * lda * 2 >= (1L << 31) || (long)K * ldb * 2 >= (1L << 31)) return MVAE_ERR_UNSUPPORTED;
+  Plan pl = make_plan_tn(M, N, K);
+  GemmArgs p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.partial = nullptr;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
+  if (pl.splits > 1) {
+    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
+    p.partial = reinterpret_cast<float*>(ws);
+  }
+  dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(256);
+  auto kern = gemm_tn_bf16_kernel<4>;
+  static bool attr_set = false;
+  if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+  hipLaunchKernelGGL(kern, grid, block, 4 * 32768, st, p);
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;

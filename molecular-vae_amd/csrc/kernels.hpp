@@ -7,6 +7,9 @@
 size_t gemm_nt_workspace_bytes(int M, int N, int K, int dtype);
 int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                    int c_dtype, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_tn_workspace_bytes(int M, int N, int K);
+int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
+                        const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, long lds_, void* dst, long ldd, void* dstT,
                           long ldt, hipStream_t st);
 size_t colsum_workspace_bytes(int M, int N);

@@ -1,46 +1,77 @@
 // Recurrent stack on gfx950: layer-wavefront schedule, one launch per wavefront step.
 // Forward cell update  = MFMA tile loop over two K-segments (x_t . W_ih^T, h_{t-1} . W_hh^T) whose output tile
-// holds the 4 gate pre-activations of the same (batch row, hidden unit) in one lane, so the gate
-// non-linearities and the state update run in the epilogue (models.py:128,164 nn.LSTM).
+// holds the 4 gate pre-activations of the same (batch row, hidden unit), so the gate non-linearities and the
+// state update run in the epilogue (models.py:128,164 nn.LSTM).
 // Backward cell update = tile loop over (dG_{t+1} . W_hh, dG^{l+1}_t . W_ih^{l+1}) + gate derivative epilogue.
+// Epilogues go through LDS: accumulators are re-laid out so that each thread owns 8 consecutive hidden units of
+// one batch row and every global access of the saved state (gates, c, h, dG, dc) is a 16-byte coalesced vector.
 #include "tile_pipe.hpp"
 #include "kernels.hpp"
 #include <stdlib.h>
 
-struct StepTaskF {
-  const void *A0, *A1, *W0, *W1;
-  long lda0, lda1, ldw0, ldw1;
-  int K0, K1;
-  const float* add; long add_ld;
-  const float* bias;
-  const float* c_prev; float* c_out;
-  void* h_out; long ldh;
-  void* hT_out; long ldT; long tcol;
-  void* g_out;
-};
-struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_j, dbg; };
-
-template <typename T> struct Vec4;   // 4 consecutive elements as one store
-template <> struct Vec4<float> { typedef float4 type; static __device__ __forceinline__ float4 make(float a, float b, float c, float d) { return make_float4(a, b, c, d); } };
-template <> struct Vec4<bf16_t> { typedef uint2 type; static __device__ __forceinline__ uint2 make(float a, float b, float c, float d) {
-  return make_uint2((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16), (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16)); } };
-
-// store v[0..3] to dstT[col0 .. col0+3] (4 consecutive batch rows of one transposed row)
-template <typename T>
-__device__ __forceinline__ void store_rows4(T* rowbase, long col0, const float (&v)[4], int nvalid) {
-  if (nvalid == 4 && ((col0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(rowbase) & 15) == 0)) {
-    *reinterpret_cast<typename Vec4<T>::type*>(rowbase + col0) = Vec4<T>::make(v[0], v[1], v[2], v[3]);
-  } else {
-    for (int r = 0; r < nvalid; ++r) TT<T>::st(rowbase + col0 + r, v[r]);
-  }
+// ---------------------------------------------------------------------------------------------- 8-wide vector I/O
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+// n valid elements (n == 8 and `vec` -> one/two 16-byte accesses; otherwise element-wise)
+template <typename T> __device__ __forceinline__ void ldn(const T* p, float (&v)[8], int n, bool vec) {
+  if (vec && n == 8) { load8<T>(p, v); return; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (e < n) ? TT<T>::ld(p + e) : 0.f;
+}
+template <typename T> __device__ __forceinline__ void stn(T* p, const float (&v)[8], int n, bool vec) {
+  if (vec && n == 8) { store8<T>(p, v); return; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) if (e < n) TT<T>::st(p + e, v[e]);
+}
+
+// gate non-linearities: exact-ish libm forms for the f32 path, v_exp_f32-based forms for the bf16 path
+template <typename T> __device__ __forceinline__ float act_sigmoid(float x);
+template <typename T> __device__ __forceinline__ float act_tanh(float x);
+template <> __device__ __forceinline__ float act_sigmoid<float>(float x) { return 1.f / (1.f + expf(-x)); }
+template <> __device__ __forceinline__ float act_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ float act_sigmoid<bf16_t>(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+template <> __device__ __forceinline__ float act_tanh<bf16_t>(float x) { return 1.f - __fdividef(2.f, 1.f + __expf(2.f * x)); }
 
 __device__ __forceinline__ int xcd_remap_r(int bid, int n) {   // contiguous tile ranges per XCD (see gemm.hip)
   const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <typename T, int BM, int BJ, int NBUF>   // NBUF == 0: generic register-staged path (any shape)
+// ---------------------------------------------------------------------------------------------- forward
+struct StepTaskF {
+  const void *A0, *A1, *W0, *W1;
+  long lda0, lda1, ldw0, ldw1;
+  int K0, K1;
+  const float* add; long add_ld;      // fp32 row-wise pre-activation addend (layer 0) or nullptr
+  const float* bias;                  // fp32 [4H] or nullptr
+  const float* c_prev; float* c_out;  // fp32 recurrent cell state (ping-pong)
+  void* c_save;                       // [B,H] dtype: cell state saved for backward
+  void* h_out; long ldh;
+  void* g_out;                        // [B,4H] dtype: post-activation gates saved for backward
+};
+struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_j, dbg, vec; };
+
+template <typename T, int BM, int BJ, int NBUF>   // NBUF == 0: generic register-staged main loop (any shape)
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   constexpr bool PIPE = NBUF > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,9 +91,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int g = 0; g < NI; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int brow[NI];
-#pragma unroll
-  for (int g = 0; g < NI; ++g) brow[g] = g * BJ + wj * 16;
 
   if constexpr (PIPE) {
     PipeSeg<BM, BN> s0, s1;
@@ -81,7 +109,10 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
     }
     tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), BJ>(smem, s0, s1, wm * WM, wj * 16, acc, tid);
   } else {
-  if (q.A0 != nullptr) {
+    int brow[NI];
+#pragma unroll
+    for (int g = 0; g < NI; ++g) brow[g] = g * BJ + wj * 16;
+    if (q.A0 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A0);
       const T* W = reinterpret_cast<const T*>(q.W0);
       const long lda = q.lda0, ldw = q.ldw0;
@@ -98,56 +129,95 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
       tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
     }
   }
+  if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.c_out[0] = 1.f; return; }   // tuning hook: main loop only
 
-  if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.t[0].c_out[0] = 1.f; return; }   // tuning hook: main loop only
-  const int j = j0 + wj * 16 + (lane & 15);
-  if (j >= H) return;
-  const int lq = lane >> 4;
-  float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
-  if (q.bias) { bi = q.bias[j]; bf = q.bias[H + j]; bg = q.bias[2 * H + j]; bo = q.bias[3 * H + j]; }
+  // ---- epilogue: accumulators -> LDS [row][gate][BJ + 4] (fp32), then one thread per (row, 8 hidden units)
+  constexpr int SJ = BJ + 4;
+  float* stg = reinterpret_cast<float*>(smem);
+  {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int g = 0; g < NI; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * WM + i * 16 + lq * 4 + r;
+          stg[(row * 4 + g) * SJ + wj * 16 + lr] = acc[i][g][r];
+        }
+  }
+  __syncthreads();
+  const int g8 = tid & 3;                      // constant per thread: 8-unit group inside the BJ = 32 tile
+  const int j8 = j0 + g8 * 8;
+  if (j8 >= H) return;
+  const int n = (H - j8 < 8) ? (H - j8) : 8;
+  const bool vec = p.vec != 0;
+  float bias[4][8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (q.bias) ldn<float>(q.bias + g * H + j8, bias[g], n, vec);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias[g][e] = 0.f;
+    }
+  }
   T* hout = reinterpret_cast<T*>(q.h_out);
   T* gout = reinterpret_cast<T*>(q.g_out);
-  T* hT = reinterpret_cast<T*>(q.hT_out);
+  T* csave = reinterpret_cast<T*>(q.c_save);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int row0 = m0 + wm * WM + i * 16 + lq * 4;
-    float hv[4] = {0.f, 0.f, 0.f, 0.f};
-    int nvalid = 0;
+  for (int it = 0; it < BM * 4 / 256; ++it) {
+    const int lrow = (tid >> 2) + it * 64;
+    const int row = m0 + lrow;
+    if (row >= B) continue;
+    float pre[4][8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + r;
-      if (row >= B) continue;
-      nvalid = r + 1;
-      float pi = acc[i][0][r] + bi, pf = acc[i][1][r] + bf, pg = acc[i][2][r] + bg, po = acc[i][3][r] + bo;
-      if (q.add) {
-        const float* a = q.add + (long)row * q.add_ld + j;
-        pi += a[0]; pf += a[H]; pg += a[2 * H]; po += a[3 * H];
-      }
-      const float ig = sigmoid_f(pi), fg = sigmoid_f(pf), gg = tanhf(pg), og = sigmoid_f(po);
-      const float cp = q.c_prev ? q.c_prev[(long)row * H + j] : 0.f;
-      const float c = fg * cp + ig * gg;
-      const float h = og * tanhf(c);
-      q.c_out[(long)row * H + j] = c;
-      TT<T>::st(hout + (long)row * q.ldh + j, h);
-      T* g4 = gout + (long)row * 4 * H + j;
-      TT<T>::st(g4, ig); TT<T>::st(g4 + H, fg); TT<T>::st(g4 + 2 * H, gg); TT<T>::st(g4 + 3 * H, og);
-      hv[r] = h;
+    for (int g = 0; g < 4; ++g) {
+      const float* s = stg + (lrow * 4 + g) * SJ + g8 * 8;
+      const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+      pre[g][0] = a.x + bias[g][0]; pre[g][1] = a.y + bias[g][1]; pre[g][2] = a.z + bias[g][2]; pre[g][3] = a.w + bias[g][3];
+      pre[g][4] = b.x + bias[g][4]; pre[g][5] = b.y + bias[g][5]; pre[g][6] = b.z + bias[g][6]; pre[g][7] = b.w + bias[g][7];
     }
-    if (hT && nvalid > 0) store_rows4<T>(hT + (long)j * q.ldT, q.tcol + row0, hv, nvalid);
+    if (q.add) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a[8];
+        ldn<float>(q.add + (long)row * q.add_ld + g * H + j8, a, n, vec);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre[g][e] += a[e];
+      }
+    }
+    float cp[8];
+    if (q.c_prev) ldn<float>(q.c_prev + (long)row * H + j8, cp, n, vec);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+    }
+    float gi[8], gf[8], gg[8], go[8], c[8], h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gi[e] = act_sigmoid<T>(pre[0][e]); gf[e] = act_sigmoid<T>(pre[1][e]); gg[e] = act_tanh<T>(pre[2][e]); go[e] = act_sigmoid<T>(pre[3][e]);
+      c[e] = gf[e] * cp[e] + gi[e] * gg[e];
+      h[e] = go[e] * act_tanh<T>(c[e]);
+    }
+    stn<float>(q.c_out + (long)row * H + j8, c, n, vec);
+    stn<T>(csave + (long)row * H + j8, c, n, vec);
+    stn<T>(hout + (long)row * q.ldh + j8, h, n, vec);
+    T* g4 = gout + (long)row * 4 * H + j8;
+    stn<T>(g4, gi, n, vec); stn<T>(g4 + H, gf, n, vec); stn<T>(g4 + 2 * H, gg, n, vec); stn<T>(g4 + 3 * H, go, n, vec);
   }
 }
 
-// ------------------------------------------------------------------------------------------------ backward
+// ---------------------------------------------------------------------------------------------- backward
 struct StepTaskB {
   const void *A0, *A1, *W0, *W1;
   long lda0, lda1, ldw0, ldw1;
   int K0, K1;
   const float* dy; long dy_ld;
-  const void* gates; const float* c; const float* c_prev;
-  const float* dc_in; float* dc_out;
-  void* dG; long ldg; void* dGT; long ldT; long tcol;
+  const void* gates; const void* c; const void* c_prev;     // dtype
+  const float* dc_in; float* dc_out;                        // fp32 ping-pong
+  void* dG; long ldg;
 };
-struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_n, dbg; };
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_n, dbg, vec; };
 
 template <typename T, int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
@@ -168,9 +238,6 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int n = 0; n < NI; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int brow[NI];
-#pragma unroll
-  for (int n = 0; n < NI; ++n) brow[n] = wn * WN + n * 16;
 
   if constexpr (PIPE) {
     PipeSeg<BM, BN> s0, s1;
@@ -189,7 +256,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
     }
     tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), 16>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
   } else {
-  if (q.A0 != nullptr) {
+    int brow[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) brow[n] = wn * WN + n * 16;
+    if (q.A0 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A0);
       const T* W = reinterpret_cast<const T*>(q.W0);
       const long lda = q.lda0, ldw = q.ldw0;
@@ -206,55 +276,82 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
       tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
     }
   }
+  if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.dc_out[0] = 1.f; return; }   // tuning hook: main loop only
 
-  if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.t[0].dc_out[0] = 1.f; return; }   // tuning hook: main loop only
-  const int lq = lane >> 4;
+  // ---- epilogue: dh tile -> LDS [row][BN + 4] (fp32), then one thread per (row, 8 hidden units)
+  constexpr int SN = BN + 4;
+  float* stg = reinterpret_cast<float*>(smem);
+  {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[(wm * WM + i * 16 + lq * 4 + r) * SN + wn * WN + n * 16 + lr] = acc[i][n][r];
+  }
+  __syncthreads();
+  constexpr int GPR = BN / 8;                  // 8-unit groups per tile row
+  const int g8 = tid % GPR;
+  const int j8 = n0 + g8 * 8;
+  if (j8 >= H) return;
+  const int n = (H - j8 < 8) ? (H - j8) : 8;
+  const bool vec = p.vec != 0;
   const T* gates = reinterpret_cast<const T*>(q.gates);
+  const T* cs = reinterpret_cast<const T*>(q.c);
+  const T* csp = reinterpret_cast<const T*>(q.c_prev);
   T* dG = reinterpret_cast<T*>(q.dG);
-  T* dGT = reinterpret_cast<T*>(q.dGT);
 #pragma unroll
-  for (int n = 0; n < NI; ++n) {
-    const int j = n0 + wn * WN + n * 16 + (lane & 15);
-    if (j >= H) continue;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int row0 = m0 + wm * WM + i * 16 + lq * 4;
-      float vi[4] = {0, 0, 0, 0}, vf[4] = {0, 0, 0, 0}, vg[4] = {0, 0, 0, 0}, vo[4] = {0, 0, 0, 0};
-      int nvalid = 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + r;
-        if (row >= B) continue;
-        nvalid = r + 1;
-        float dh = acc[i][n][r];
-        if (q.dy) dh += q.dy[(long)row * q.dy_ld + j];
-        const T* g4 = gates + (long)row * 4 * H + j;
-        const float ig = TT<T>::ld(g4), fg = TT<T>::ld(g4 + H), gg = TT<T>::ld(g4 + 2 * H), og = TT<T>::ld(g4 + 3 * H);
-        const long o = (long)row * H + j;
-        const float c = q.c[o];
-        const float cp = q.c_prev ? q.c_prev[o] : 0.f;
-        const float tc = tanhf(c);
-        const float d_o = dh * tc;
-        const float dc = dh * og * (1.f - tc * tc) + (q.dc_in ? q.dc_in[o] : 0.f);
-        q.dc_out[o] = dc * fg;
-        vi[r] = dc * gg * ig * (1.f - ig);
-        vf[r] = dc * cp * fg * (1.f - fg);
-        vg[r] = dc * ig * (1.f - gg * gg);
-        vo[r] = d_o * og * (1.f - og);
-        T* d4 = dG + (long)row * q.ldg + j;
-        TT<T>::st(d4, vi[r]); TT<T>::st(d4 + H, vf[r]); TT<T>::st(d4 + 2 * H, vg[r]); TT<T>::st(d4 + 3 * H, vo[r]);
-      }
-      if (dGT && nvalid > 0) {
-        store_rows4<T>(dGT + (long)j * q.ldT, q.tcol + row0, vi, nvalid);
-        store_rows4<T>(dGT + ((long)H + j) * q.ldT, q.tcol + row0, vf, nvalid);
-        store_rows4<T>(dGT + ((long)2 * H + j) * q.ldT, q.tcol + row0, vg, nvalid);
-        store_rows4<T>(dGT + ((long)3 * H + j) * q.ldT, q.tcol + row0, vo, nvalid);
-      }
+  for (int it = 0; it < BM * GPR / 256; ++it) {
+    const int lrow = tid / GPR + it * (256 / GPR);
+    const int row = m0 + lrow;
+    if (row >= B) continue;
+    float dh[8];
+    {
+      const float* s = stg + lrow * SN + g8 * 8;
+      const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+      dh[0] = a.x; dh[1] = a.y; dh[2] = a.z; dh[3] = a.w; dh[4] = b.x; dh[5] = b.y; dh[6] = b.z; dh[7] = b.w;
     }
+    if (q.dy) {
+      float a[8];
+      ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dh[e] += a[e];
+    }
+    float gi[8], gf[8], gg[8], go[8], c[8], cp[8], dci[8];
+    const T* g4 = gates + (long)row * 4 * H + j8;
+    ldn<T>(g4, gi, n, vec); ldn<T>(g4 + H, gf, n, vec); ldn<T>(g4 + 2 * H, gg, n, vec); ldn<T>(g4 + 3 * H, go, n, vec);
+    const long o = (long)row * H + j8;
+    ldn<T>(cs + o, c, n, vec);
+    if (csp) ldn<T>(csp + o, cp, n, vec);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+    }
+    if (q.dc_in) ldn<float>(q.dc_in + o, dci, n, vec);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dci[e] = 0.f;
+    }
+    float di[8], df[8], dg[8], dO[8], dco[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float tc = act_tanh<T>(c[e]);
+      const float d_o = dh[e] * tc;
+      const float dc = dh[e] * go[e] * (1.f - tc * tc) + dci[e];
+      dco[e] = dc * gf[e];
+      di[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
+      df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+      dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
+      dO[e] = d_o * go[e] * (1.f - go[e]);
+    }
+    stn<float>(q.dc_out + o, dco, n, vec);
+    T* d4 = dG + (long)row * q.ldg + j8;
+    stn<T>(d4, di, n, vec); stn<T>(d4 + H, df, n, vec); stn<T>(d4 + 2 * H, dg, n, vec); stn<T>(d4 + 3 * H, dO, n, vec);
   }
 }
 
-// ------------------------------------------------------------------------------------------------ host drivers
+// ---------------------------------------------------------------------------------------------- host drivers
 #define MVAE_STEP_LAUNCH(KERN)                                                                                     \
   do {                                                                                                               \
     auto kern = KERN;                                                                                                \
@@ -263,7 +360,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
   } while (0)
 
-// tuning knobs (read once): MVAE_NBUF_FWD / MVAE_NBUF_BWD = LDS ring depth, MVAE_BM = force row-tile, MVAE_DBG bit0 = skip epilogue
+// tuning knobs (read per call): MVAE_NBUF_FWD / MVAE_NBUF_BWD = LDS ring depth, MVAE_BM = force row tile, MVAE_DBG bit0 = skip epilogue
 static int tune_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -272,6 +369,7 @@ static int tune_int(const char* name, int dflt) {
 static inline const char* adv(const void* p, long elems, int dtype) {
   return reinterpret_cast<const char*>(p) + elems * (dtype == MVAE_BF16 ? 2 : 4);
 }
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (!d) return MVAE_ERR_INVALID;
@@ -281,7 +379,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   const int NL = d->layers, T = d->T, B = d->B, H = d->H, dt = d->dtype;
   const int epc = (dt == MVAE_BF16) ? 8 : 4;
   for (int l = 0; l < NL; ++l) {
-    if (!d->w_hh[l] || !d->hs[l] || !d->cs[l] || !d->gates[l]) return MVAE_ERR_INVALID;
+    if (!d->w_hh[l] || !d->hs[l] || !d->cs[l] || !d->gates[l] || !d->cstate[l]) return MVAE_ERR_INVALID;
     if (l > 0 && !d->w_ih[l]) return MVAE_ERR_INVALID;
     if (d->ldw_hh[l] % epc) return MVAE_ERR_INVALID;
     if (l > 0 && d->ldw_ih[l] % epc) return MVAE_ERR_INVALID;
@@ -291,15 +389,23 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (d->ldh % epc) return MVAE_ERR_INVALID;
   const int BM = tune_int("MVAE_BM", (B > 64 && ((B + 127) / 128) * ((H + 31) / 32) * NL >= 256) ? 128 : 64);
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
-  // deep-pipelined LDS-direct path: whole K-steps, 16-byte aligned rows, operands < 2 GiB
+  // deep-pipelined LDS-direct main loop: whole K-steps, 16-byte aligned rows, operands < 2 GiB
   bool pipe = (H % ke == 0) && (d->ldh % (16 / sz) == 0) && ((long)B * d->ldh * sz < (1L << 31)) && (!d->x0 || (d->in0 % ke == 0 && d->x0_ld % (16 / sz) == 0)) &&
               (!d->h0[0] || d->ldh0 % (16 / sz) == 0);
+  // 16-byte vector epilogue: 8-unit groups aligned in every array it touches
+  bool vec = (H % 8 == 0) && (d->ldh % 8 == 0) && (!d->add0 || (al16(d->add0) && d->add0_tstride % 4 == 0));
   for (int l = 0; l < NL; ++l) {
     if ((4L * H) * d->ldw_hh[l] * sz >= (1L << 31) || d->ldw_hh[l] % (16 / sz)) pipe = false;
     if ((l > 0 || d->x0) && ((4L * H) * d->ldw_ih[l] * sz >= (1L << 31) || d->ldw_ih[l] % (16 / sz))) pipe = false;
+    if (!al16(d->hs[l]) || !al16(d->cs[l]) || !al16(d->gates[l]) || !al16(d->cstate[l]) || (d->bias[l] && !al16(d->bias[l]))) vec = false;
   }
   StepArgsF a;
-  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + 31) / 32;
+  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + 31) / 32; a.vec = vec ? 1 : 0;
+  a.dbg = tune_int("MVAE_DBG", 0);
+  const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", 4) : 0;
+  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 128) * KB;
+  const size_t stage_bytes = (size_t)BM * 4 * (32 + 4) * sizeof(float);     // epilogue staging tile
+  if (lds < stage_bytes) lds = stage_bytes;
   for (int dd = 0; dd < T + NL - 1; ++dd) {
     int n = 0;
     for (int l = 0; l < NL; ++l) {
@@ -320,17 +426,14 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       q.lda1 = (t > 0) ? d->ldh : d->ldh0;
       q.K1 = H; q.W1 = d->w_hh[l]; q.ldw1 = d->ldw_hh[l];
       q.bias = d->bias[l];
-      q.c_prev = (t > 0) ? d->cs[l] + (long)(t - 1) * B * H : nullptr;
-      q.c_out = d->cs[l] + (long)t * B * H;
+      q.c_prev = (t > 0) ? d->cstate[l] + (long)((t - 1) & 1) * B * H : nullptr;
+      q.c_out = d->cstate[l] + (long)(t & 1) * B * H;
+      q.c_save = const_cast<char*>(adv(d->cs[l], (long)t * B * H, dt));
       q.h_out = const_cast<char*>(adv(d->hs[l], (long)t * B * d->ldh, dt)); q.ldh = d->ldh;
-      q.hT_out = d->hsT[l]; q.ldT = d->ldT; q.tcol = (long)t * B;
       q.g_out = const_cast<char*>(adv(d->gates[l], (long)t * B * 4 * H, dt));
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_j), block(256);
-    const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", BM == 128 ? 4 : 4) : 0;
-    const size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 128) * KB;
-    a.dbg = tune_int("MVAE_DBG", 0);
 #define FWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
     if (dt == MVAE_BF16) {
       FWD_CASE(bf16_t, 128, 0) FWD_CASE(bf16_t, 128, 3) FWD_CASE(bf16_t, 128, 4) FWD_CASE(bf16_t, 128, 5)
@@ -363,12 +466,19 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   const int BM = tune_int("MVAE_BM", (B > 64 && ((B + 127) / 128) * ((H + 63) / 64) * NL >= 200) ? 128 : 64);
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
   bool pipe = ((4 * H) % ke == 0) && ((long)B * ldg * sz < (1L << 31)) && (ldg % (16 / sz) == 0);
+  bool vec = (H % 8 == 0) && (ldg % 8 == 0) && al16(d->dy) && (d->dy_ld % 4 == 0);
   for (int l = 0; l < NL; ++l) {
     if ((long)H * d->ldw_hhT[l] * sz >= (1L << 31) || d->ldw_hhT[l] % (16 / sz)) pipe = false;
     if (l > 0 && ((long)H * d->ldw_ihT[l] * sz >= (1L << 31) || d->ldw_ihT[l] % (16 / sz))) pipe = false;
+    if (!al16(d->cs[l]) || !al16(d->gates[l]) || !al16(d->dG[l]) || !al16(d->dstate[l])) vec = false;
   }
   StepArgsB a;
-  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + 63) / 64;
+  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + 63) / 64; a.vec = vec ? 1 : 0;
+  a.dbg = tune_int("MVAE_DBG", 0);
+  const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
+  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 64) * KB;
+  const size_t stage_bytes = (size_t)BM * (64 + 4) * sizeof(float);
+  if (lds < stage_bytes) lds = stage_bytes;
   for (int e = T + NL - 2; e >= 0; --e) {
     int n = 0;
     for (int l = 0; l < NL; ++l) {
@@ -381,18 +491,14 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       q.lda1 = ldg; q.K1 = 4 * H; q.W1 = (l < NL - 1) ? d->w_ihT[l + 1] : nullptr; q.ldw1 = (l < NL - 1) ? d->ldw_ihT[l + 1] : 0;
       q.dy = (l == NL - 1) ? d->dy + (long)t * B * d->dy_ld : nullptr; q.dy_ld = d->dy_ld;
       q.gates = adv(d->gates[l], (long)t * B * 4 * H, dt);
-      q.c = d->cs[l] + (long)t * B * H;
-      q.c_prev = (t > 0) ? d->cs[l] + (long)(t - 1) * B * H : nullptr;
+      q.c = adv(d->cs[l], (long)t * B * H, dt);
+      q.c_prev = (t > 0) ? adv(d->cs[l], (long)(t - 1) * B * H, dt) : nullptr;
       q.dc_in = (t < T - 1) ? d->dstate[l] + (long)((t + 1) & 1) * B * H : nullptr;
       q.dc_out = d->dstate[l] + (long)(t & 1) * B * H;
       q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * ldg, dt)); q.ldg = ldg;
-      q.dGT = d->dGT[l]; q.ldT = d->ldT; q.tcol = (long)t * B;
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n), block(256);
-    const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
-    const size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 64) * KB;
-    a.dbg = tune_int("MVAE_DBG", 0);
 #define BWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<TT_, BM_, 64, NB_>)); continue; }
     if (dt == MVAE_BF16) {
       BWD_CASE(bf16_t, 128, 0) BWD_CASE(bf16_t, 128, 3) BWD_CASE(bf16_t, 128, 4) BWD_CASE(bf16_t, 128, 5) BWD_CASE(bf16_t, 128, 6)

@@ -153,3 +153,130 @@ __device__ __forceinline__ void tile_gemm_pipe(char* smem, const PipeSeg<BM, BN>
   }
   __builtin_amdgcn_s_barrier();                               // LDS free for the caller (epilogue scratch / next use)
 }
+
+
+// =====================================================================================================================
+// TN form (bf16): C[m][n] = sum_k A[k][m] * B[k][n] with both operands K-major in memory (row = k, m / n contiguous):
+// the weight-gradient contraction dW = dG^T . X reads dG [T*B, 4H] and X [T*B, H] exactly as the step kernels wrote them,
+// so no transposed copies exist anywhere.  LDS stage = 64 k-rows x 128 columns per operand (256-byte rows); the MFMA
+// fragments (8 consecutive k of one column per lane) come from the hardware transposed read ds_read_b64_tr_b16
+// (4 k-rows x 16 columns per 16-lane group).  Bank conflicts: 8 rows of one half-wave would hit the same 8 banks, so the
+// 32-byte column block index is XOR-ed with f(k) = (k & 3) | ((k >> 3) & 1) << 2 -- applied to the LDS-DMA SOURCE address
+// (the LDS image itself is lane-linear) and to the read address.
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr64(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+struct PipeSegTN {
+  __amdgpu_buffer_rsrc_t ra, rb;
+  uint32_t offA[4], offB[4];       // per-thread byte offsets of its 4 + 4 LDS-DMA pieces at k-step 0
+  uint32_t kstepA, kstepB;         // bytes per 64-row K-step
+  int nk;
+};
+
+__device__ __forceinline__ uint32_t tn_f(int krow) { return (uint32_t)((krow & 3) | (((krow >> 3) & 1) << 2)); }
+
+// A: [K][lda] elements (bf16), tile columns [m0, m0+128); B likewise with n0.  K rows beyond the matrix read as zero
+// through the descriptor bound (num_records = K * ld * 2).
+__device__ __forceinline__ void pipe_seg_tn_init(PipeSegTN& s, const void* A, long lda, int m0, const void* B, long ldb, int n0,
+                                                 int K, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  s.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A), 0, (int)((long)K * lda * 2), 0x00020000);
+  s.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(B), 0, (int)((long)K * ldb * 2), 0x00020000);
+  s.nk = (K + 63) / 64;
+  s.kstepA = (uint32_t)(64 * lda * 2);
+  s.kstepB = (uint32_t)(64 * ldb * 2);
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ii = i * 4 + wave;                 // 1-KiB piece index inside the operand's 16-KiB stage half
+    const int krow = ii * 4 + (lane >> 4), pc = lane & 15;
+    const uint32_t lc = (uint32_t)((((pc >> 1) ^ tn_f(krow)) << 1) | (pc & 1));   // logical 16-byte chunk fetched into physical chunk pc
+    s.offA[i] = (uint32_t)krow * (uint32_t)(lda * 2) + (uint32_t)(m0 * 2) + lc * 16u;
+    s.offB[i] = (uint32_t)krow * (uint32_t)(ldb * 2) + (uint32_t)(n0 * 2) + lc * 16u;
+  }
+#endif
+}
+
+template <int NBUF>
+__device__ __forceinline__ void pipe_tn_issue(char* smem, const PipeSegTN& s, int st, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  char* stage = smem + (st % NBUF) * 32768;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + (i * 4 + wave) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + (uint32_t)st * s.kstepA, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + 16384 + (i * 4 + wave) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + (uint32_t)st * s.kstepB, 0, 0, 0);
+  }
+#endif
+}
+
+template <int I, int N> struct FragReadTN {   // fragment I of N: two transposed reads (k rows 8g..8g+3 and 8g+4..8g+7)
+  template <int KOFF>
+  static __device__ __forceinline__ void run(u32x4 (&dst)[N], const uint32_t (&addr)[N], uint32_t st) {
+    const u32x2 lo = lds_read_tr64<KOFF>(st + addr[I]);
+    const u32x2 hi = lds_read_tr64<KOFF + 1024>(st + addr[I]);
+    dst[I] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    FragReadTN<I + 1, N>::template run<KOFF>(dst, addr, st);
+  }
+};
+template <int N> struct FragReadTN<N, N> {
+  template <int KOFF> static __device__ __forceinline__ void run(u32x4 (&)[N], const uint32_t (&)[N], uint32_t) {}
+};
+
+// 128 x 128 tile, 4 waves (2 x 2), wave tile 64 x 64 (MI = NI = 4).  smem: NBUF * 32 KiB.
+template <int NBUF>
+__device__ __forceinline__ void tile_gemm_pipe_tn(char* smem, const PipeSegTN& s, int wm, int wn, f32x4 (&acc)[4][4], int tid) {
+  constexpr int LPS = 8;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = s.nk;
+  if (nk <= 0) return;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const uint32_t f = (uint32_t)(q | ((g & 1) << 2));
+  uint32_t addrA[4], addrB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    addrA[i] = (uint32_t)(8 * g + q) * 256u + ((((uint32_t)(wm * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u;
+    addrB[i] = (uint32_t)(8 * g + q) * 256u + ((((uint32_t)(wn * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u + 16384u;
+  }
+#pragma unroll
+  for (int st = 0; st < NBUF - 1; ++st)
+    if (st < nk) pipe_tn_issue<NBUF>(smem, s, st, wave);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NBUF - 1 < nk) pipe_tn_issue<NBUF>(smem, s, kt + NBUF - 1, wave);
+    const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * 32768);
+    u32x4 a0[4], b0[4], a1[4], b1[4];
+    FragReadTN<0, 4>::run<0>(a0, addrA, st);          // k rows 0..31 of the stage
+    FragReadTN<0, 4>::run<0>(b0, addrB, st);
+    wait_lgkmcnt<0>();
+    FragReadTN<0, 4>::run<8192>(a1, addrA, st);       // k rows 32..63: in flight under the first 16 MFMAs
+    FragReadTN<0, 4>::run<8192>(b1, addrB, st);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
+    wait_lgkmcnt<0>();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        mma16<bf16_t>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
+  }
+  __builtin_amdgcn_s_barrier();
+}

@@ -158,6 +158,38 @@ def _params_key(params):
     return (L.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params)
 
 
+def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh):
+    """dW_ih, dW_hh, db of every layer from the saved pre-activation gradients dG [T*B, 4H] and layer outputs hs [T*B, H].
+    bf16: hardware-transposed TN GEMM straight from the K-major buffers; f32: explicit transposes + NT GEMM."""
+    G4, TB = 4 * H, Lq * B
+    f32 = torch.float32
+    if dt == torch.bfloat16:
+        for l in range(NL):
+            a = dG[l].view(TB, ldg)
+            x = hs[l].view(TB, ldh)
+            if Lq > 1:
+                ops.gemm_tn(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldg, ldb=ldh)
+            if l > 0:
+                ops.gemm_tn(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
+            ops.colsum_t(a, TB, G4, grads[f"{prefix}.bias_ih_l{l}"], ldx=ldg)
+            grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
+        return
+    ldT = _pad(TB, 8) + 8          # +8: the time-shifted GEMM may over-read one chunk into zero pad
+    hsT_prev = None
+    for l in range(NL):
+        dGT = ws.get("wg_dGT", (G4, ldT), f32, dev)
+        hsT = ws.get(f"wg_hsT{l & 1}", (H, ldT), f32, dev)
+        ops.cast_transpose(dG[l].view(TB, ldg), TB, G4, dstT=dGT, lds=ldg)
+        ops.cast_transpose(hs[l].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
+        if Lq > 1:
+            ops.gemm_nt(dGT[:, B:], hsT, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
+        if l > 0:
+            ops.gemm_nt(dGT, hsT_prev, grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
+        ops.rowsum(dGT, G4, TB, grads[f"{prefix}.bias_ih_l{l}"])
+        grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
+        hsT_prev = hsT
+
+
 class Lambda(nn.Module):
     """models.py:80-94: z_mean / z_log_var heads + reparameterisation; caches ``.mu`` / ``.log_v``."""
 
@@ -275,8 +307,6 @@ class _EncoderFn(torch.autograd.Function):
         ws.generation += 1
         f32 = torch.float32
         G4 = 4 * H
-        TB = Lq * B
-        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
         # K1: embedding folded into the layer-0 input projection: table = E . W_ih0^T + (b_ih0 + b_hh0)
         tbl = ws.get("tbl", (Cv, G4), f32, dev)
         Ep = P["E_p"].shape[1]
@@ -285,13 +315,13 @@ class _EncoderFn(torch.autograd.Function):
         ops.gather_rows_tb(idx, tbl, gx0, B, Lq, Cv, G4)
         # K2: 3-layer LSTM, f32 MFMA
         hs = [ws.get(f"hs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
-        hsT = [ws.get(f"hsT{l}", (H, ldT), f32, dev) for l in range(NL)]
         cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
         gates = [ws.get(f"gates{l}", (Lq, B, G4), f32, dev) for l in range(NL)]
+        cstate = [ws.get(f"cstate{l}", (2, B, H), f32, dev) for l in range(NL)]
         w_ih = [None] + [getattr(g, f"weight_ih_l{l}") for l in range(1, NL)]
         w_hh = [getattr(g, f"weight_hh_l{l}") for l in range(NL)]
         ops.rnn_fwd(L.CELL_LSTM, f32, Lq, B, H, gx0, B * G4, w_ih, [H] * NL, w_hh, [H] * NL, [None] + P["bias"][1:],
-                    hs, H, hsT, ldT, cs, gates)
+                    hs, H, cs, gates, cstate, tag="enc_lstm_fwd")
         # K3: conv stack over the hidden axis, sequence position = channel (models.py:129-131)
         c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
         k = c1.kernel_size
@@ -333,7 +363,6 @@ class _EncoderFn(torch.autograd.Function):
         H, NL, Cv, E = g.hidden_size, g.num_layers, mod.embedding.num_embeddings, g.input_size
         o = mod.lmbd.z_mean.out_features
         G4, TB = 4 * H, Lq * B
-        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
         Bp = _pad(B, 4)
         P = mod._packed
         params = list(mod.parameters())
@@ -390,21 +419,13 @@ class _EncoderFn(torch.autograd.Function):
                             grads["conv_1.0.weight"], grads["conv_1.0.bias"], dhs, (H, B * H, 1))
         # K2 backward (reverse wavefront) + weight gradients
         hs = [W(f"hs{l}", (Lq, B, H)) for l in range(NL)]
-        hsT = [W(f"hsT{l}", (H, ldT)) for l in range(NL)]
         cs = [W(f"cs{l}", (Lq, B, H)) for l in range(NL)]
         gates = [W(f"gates{l}", (Lq, B, G4)) for l in range(NL)]
         dG = [W(f"dG{l}", (Lq, B, G4)) for l in range(NL)]
-        dGT = [W(f"dGT{l}", (G4, ldT)) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, H, cs, gates,
-                    dG, dGT, ldT, dstate)
-        for l in range(NL):
-            if Lq > 1:
-                ops.gemm_nt(dGT[l][:, B:], hsT[l], grads[f"gru.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
-            if l > 0:
-                ops.gemm_nt(dGT[l], hsT[l - 1], grads[f"gru.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
-            ops.rowsum(dGT[l], G4, TB, grads[f"gru.bias_ih_l{l}"])
-            grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
+                    dG, dstate, tag="enc_lstm_bwd")
+        _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, H)
         # K1 backward: table gradient, then embedding / W_ih0
         dtbl = W("dtbl", (Cv, G4))
         ops.scatter_rows_tb(idx, dG[0], dtbl, B, Lq, Cv, G4)
@@ -485,7 +506,6 @@ class _DecoderFn(torch.autograd.Function):
         om = mod.decoded_mean.module[0]
         Cv = om.out_features
         G4, TB = 4 * H, Lq * B
-        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
         P = mod._pack(dev)
         ws = mod._ws
         ws.generation += 1
@@ -499,11 +519,11 @@ class _DecoderFn(torch.autograd.Function):
         # K7: 4-layer LSTM wavefront
         ldh = H + _LDPAD
         hs = [ws.get(f"hs{l}", (Lq, B, ldh), dt, dev) for l in range(NL)]
-        hsT = [ws.get(f"hsT{l}", (H, ldT), dt, dev) for l in range(NL)]
-        cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
+        cs = [ws.get(f"cs{l}", (Lq, B, H), dt, dev) for l in range(NL)]
         gates = [ws.get(f"gates{l}", (Lq, B, G4), dt, dev) for l in range(NL)]
+        cstate = [ws.get(f"cstate{l}", (2, B, H), f32, dev) for l in range(NL)]
         ops.rnn_fwd(L.CELL_LSTM, dt, Lq, B, H, gx0, 0, P["Wih"], [P["ldw"]] * NL, P["Whh"], [P["ldw"]] * NL, [None] + P["bias"][1:],
-                    hs, ldh, hsT, ldT, cs, gates, tag="dec_lstm_fwd")
+                    hs, ldh, cs, gates, cstate, tag="dec_lstm_fwd")
         # K8: output head + softmax over the class axis
         logits = ws.get("logits", (TB, Cv), f32, dev)
         ops.gemm_nt(hs[-1].view(TB, ldh), P["Wout"], logits, TB, Cv, H, bias=om.bias)
@@ -529,7 +549,6 @@ class _DecoderFn(torch.autograd.Function):
         om = mod.decoded_mean.module[0]
         Cv = om.out_features
         G4, TB = 4 * H, Lq * B
-        ldT = _pad(TB, 8) + 8      # +8: the time-shifted weight-gradient GEMM may over-read one chunk into zero pad
         Cp = _pad(Cv, 8)
         Bp = _pad(B, 4)
         P = mod._packed
@@ -545,30 +564,32 @@ class _DecoderFn(torch.autograd.Function):
         W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
         ldh, ldg = H + _LDPAD, G4 + _LDPAD
         hs = [W(f"hs{l}", (Lq, B, ldh), dt) for l in range(NL)]
-        hsT = [W(f"hsT{l}", (H, ldT), dt) for l in range(NL)]
-        cs = [W(f"cs{l}", (Lq, B, H)) for l in range(NL)]
+        cs = [W(f"cs{l}", (Lq, B, H), dt) for l in range(NL)]
         gates = [W(f"gates{l}", (Lq, B, G4), dt) for l in range(NL)]
         # K8 backward
-        dl = W("dl", (TB, Cp), dt); dlT = W("dlT", (Cv, ldT), dt)
-        ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
-        ops.gemm_nt(dlT, hsT[-1], grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
-        ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
+        dl = W("dl", (TB + 8, Cp), dt)[:TB]      # +8 rows: the TN tile reads 256-byte row segments past the last row
+        if dt == torch.bfloat16:
+            ops.softmax_tb_bwd(recon, drecon, dl, None, B, Lq, Cv)
+            ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=Cp, ldb=ldh)
+            dbp = W("dbout_p", (Cp,))
+            ops.colsum_t(dl, TB, Cp, dbp, ldx=Cp)
+            grads["decoded_mean.module.0.bias"].copy_(dbp[:Cv])
+        else:
+            ldT = _pad(TB, 8) + 8
+            dlT = W("dlT", (Cv, ldT), dt); hsT = W("wg_hsT_out", (H, ldT), dt)
+            ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
+            ops.cast_transpose(hs[-1].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
+            ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
+            ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
         dy = W("dy", (TB, H))
         ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
         # K7 backward
         dG = [W(f"dG{l}", (Lq, B, ldg), dt) for l in range(NL)]
-        dGT = [W(f"dGT{l}", (G4, ldT), dt) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [P["ldwT"]] * NL, P["WihT"], [P["ldwT"]] * NL, dy, H, hs, ldh, cs, gates,
-                    dG, dGT, ldT, dstate, ldg=ldg, tag="dec_lstm_bwd")
+                    dG, dstate, ldg=ldg, tag="dec_lstm_bwd")
         with ops._Timed("dec_lstm_wgrad"):
-            for l in range(NL):
-                if Lq > 1:
-                    ops.gemm_nt(dGT[l][:, B:], hsT[l], grads[f"gru.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
-                if l > 0:
-                    ops.gemm_nt(dGT[l], hsT[l - 1], grads[f"gru.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
-                ops.rowsum(dGT[l], G4, TB, grads[f"gru.bias_ih_l{l}"])
-                grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
+            _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh)
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
         dgx0 = W("dgx0", (B, ldg))           # pad columns of dG are zero, so the padded time sum is too
         ops.timesum(dG[0], Lq, B, ldg, dgx0)

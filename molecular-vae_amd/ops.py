@@ -65,6 +65,29 @@ def gemm_nt(A, B, out, M, N, K, lda=None, ldb=None, ldc=None, bias=None, act=L.A
     return out
 
 
+def gemm_tn(A, B, out, M, N, K, lda=None, ldb=None, ldc=None, bias=None, act=L.ACT_NONE, accumulate=False):
+    """out[M,N] = act(A[:K,:M]^T . B[:K,:N] + bias): A [K, lda], B [K, ldb] bf16, K-major (weight gradients)."""
+    lib = L.load()
+    dt = dt_code(A.dtype)
+    assert B.dtype == A.dtype
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    ldc = out.stride(0) if ldc is None else ldc
+    need = lib.mvae_gemm_tn_workspace(M, N, K, dt)
+    ws = Scratch.get(need, A.device) if need else None
+    check(lib.mvae_gemm_tn(dt, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, dt_code(out.dtype), ptr(bias), act,
+                           1 if accumulate else 0, ptr(ws), need, stream_ptr()), "mvae_gemm_tn")
+    return out
+
+
+def colsum_t(X, M, N, out, ldx=None):
+    lib = L.load()
+    need = lib.mvae_colsum_t_workspace(M, N)
+    ws = Scratch.get(need, X.device)
+    check(lib.mvae_colsum_t(dt_code(X.dtype), M, N, ptr(X), X.stride(0) if ldx is None else ldx, ptr(out), ptr(ws), need,
+                            stream_ptr()), "mvae_colsum_t")
+
+
 def cast_transpose(src, R, C_, dst=None, dstT=None, lds=None):
     lib = L.load()
     lds = src.stride(0) if lds is None else lds
@@ -164,7 +187,7 @@ def _fill(arr, tensors):
         arr[i] = t.data_ptr() if t is not None else None
 
 
-def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, hsT, ldT, cs, gates,
+def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, cs, gates, cstate,
             x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, tag=None):
     d = L.RnnFwdDesc()
     NL = len(w_hh)
@@ -182,18 +205,17 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
     d.ldh0 = ldh0
     d.lengths = lengths.data_ptr() if lengths is not None else None
     _fill(d.hs, hs); d.ldh = ldh
-    if hsT is not None:
-        _fill(d.hsT, hsT)
-    d.ldT = ldT
     if cs is not None:
         _fill(d.cs, cs)
     _fill(d.gates, gates)
+    if cstate is not None:
+        _fill(d.cstate, cstate)
     with _Timed(tag):
         check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
 
 
-def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dGT, ldT, dstate,
-            ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dGhT=None, dh0=None, tag=None):
+def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dstate,
+            ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dh0=None, tag=None):
     d = L.RnnBwdDesc()
     NL = len(w_hhT)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
@@ -214,13 +236,8 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
         _fill(d.cs, cs)
     _fill(d.gates, gates); _fill(d.dG, dG)
     d.ldg = ldg if ldg is not None else {"LSTM": 4, "GRU": 3}["LSTM" if cell == L.CELL_LSTM else "GRU"] * H
-    if dGT is not None:
-        _fill(d.dGT, dGT)
-    d.ldT = ldT
     if dGh is not None:
         _fill(d.dGh, dGh)
-    if dGhT is not None:
-        _fill(d.dGhT, dGhT)
     _fill(d.dstate, dstate)
     if dh0 is not None:
         _fill(d.dh0, dh0)

@@ -18,7 +18,6 @@ dev = torch.device("cuda")
 dt = torch.bfloat16
 G4 = 4 * H
 ldw, ldwT, ldh, ldg = H + PAD, G4 + PAD, H + PAD, G4 + PAD
-ldT = (T * B + 7) // 8 * 8 + 8
 g = torch.Generator(device="cuda").manual_seed(0)
 rnd = lambda *s: (torch.randn(*s, device=dev, generator=g) * 0.05)
 
@@ -29,28 +28,27 @@ WhhT = [rnd(H, ldwT).to(dt) for _ in range(NL)]
 bias = [None] + [rnd(G4) for _ in range(NL - 1)]
 gx0 = rnd(B, G4)
 hs = [torch.zeros(T, B, ldh, device=dev, dtype=dt) for _ in range(NL)]
-hsT = [torch.zeros(H, ldT, device=dev, dtype=dt) for _ in range(NL)]
-cs = [torch.zeros(T, B, H, device=dev) for _ in range(NL)]
+cs = [torch.zeros(T, B, H, device=dev, dtype=dt) for _ in range(NL)]
+cstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
 gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
 dG = [torch.zeros(T, B, ldg, device=dev, dtype=dt) for _ in range(NL)]
-dGT = [torch.zeros(G4, ldT, device=dev, dtype=dt) for _ in range(NL)]
 dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
 dy = rnd(T * B, H)
 
 
 def fwd():
-    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, 0, Wih, [ldw] * NL, Whh, [ldw] * NL, bias, hs, ldh, hsT, ldT, cs, gates)
+    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, 0, Wih, [ldw] * NL, Whh, [ldw] * NL, bias, hs, ldh, cs, gates, cstate)
 
 
 def bwd():
-    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, WhhT, [ldwT] * NL, WihT, [ldwT] * NL, dy, H, hs, ldh, cs, gates, dG, dGT, ldT, dstate, ldg=ldg)
+    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, WhhT, [ldwT] * NL, WihT, [ldwT] * NL, dy, H, hs, ldh, cs, gates, dG, dstate, ldg=ldg)
 
 
 dW = torch.zeros(G4, H, device=dev)
 
 
 def gemm():
-    ops.gemm_nt(dGT[1], hsT[0], dW, G4, H, T * B, lda=ldT, ldb=ldT)
+    ops.gemm_tn(dG[1].view(T * B, ldg), hs[0].view(T * B, ldh), dW, G4, H, T * B, lda=ldg, ldb=ldh)
 
 
 def timeit(fn, n=5):

@@ -56,68 +56,10 @@ def t_cast_transpose():
 
 def t_lstm(dt, tol, T=7, B=5, H=32, NL=2, In=16):
     section(f"lstm fwd/bwd {dt} T={T} B={B} H={H} NL={NL}")
-    rs = np.random.RandomState(2)
-    G4 = 4 * H
-    p = {}
-    for l in range(NL):
-        inp = In if l == 0 else H
-        p[f"g.weight_ih_l{l}"] = rs.uniform(-0.4, 0.4, (G4, inp)); p[f"g.weight_hh_l{l}"] = rs.uniform(-0.4, 0.4, (G4, H))
-        p[f"g.bias_ih_l{l}"] = rs.uniform(-0.2, 0.2, G4); p[f"g.bias_hh_l{l}"] = rs.uniform(-0.2, 0.2, G4)
-    if dt == torch.bfloat16:        # make the weights exactly representable so the comparison isolates kernel arithmetic
-        for k in p:
-            if "weight" in k:
-                p[k] = torch.from_numpy(p[k]).bfloat16().double().numpy()
-    x = rs.standard_normal((T, B, In))
-    y, caches = O.lstm_fwd(x, p, "g", NL)
-    dy = rs.standard_normal((T, B, H))
-    grads = {}
-    dx = O.lstm_bwd(dy, caches, grads, "g")
-    # HIP: layer-0 input projection as addend
-    f32 = torch.float32
-    tt = lambda a, d=f32: torch.from_numpy(np.ascontiguousarray(a).astype(np.float32)).to(dev).to(d)
-    gx0 = tt((x.reshape(T * B, In) @ p["g.weight_ih_l0"].T + p["g.bias_ih_l0"] + p["g.bias_hh_l0"]).reshape(T, B, G4))
-    ldT = (T * B + 7) // 8 * 8 + 8
-    hs = [torch.zeros(T, B, H, device=dev, dtype=dt) for _ in range(NL)]
-    hsT = [torch.zeros(H, ldT, device=dev, dtype=dt) for _ in range(NL)]
-    cs = [torch.zeros(T, B, H, device=dev) for _ in range(NL)]
-    gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
-    w_ih = [None] + [tt(p[f"g.weight_ih_l{l}"], dt) for l in range(1, NL)]
-    w_hh = [tt(p[f"g.weight_hh_l{l}"], dt) for l in range(NL)]
-    bias = [None] + [tt(p[f"g.bias_ih_l{l}"] + p[f"g.bias_hh_l{l}"]) for l in range(1, NL)]
-    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, B * G4, w_ih, [H] * NL, w_hh, [H] * NL, bias, hs, H, hsT, ldT, cs, gates)
-    torch.cuda.synchronize()
-    for l in range(NL):
-        print(f"  fwd layer {l}: h rel={rel(hs[l].float().cpu().numpy(), caches[l][1]):.3e} c rel={rel(cs[l].cpu().numpy(), caches[l][2]):.3e} "
-              f"gates rel={rel(gates[l].float().cpu().numpy(), caches[l][3]):.3e} "
-              f"hT rel={rel(hsT[l][:, :T * B].float().cpu().numpy(), caches[l][1].reshape(T * B, H).T):.3e}", flush=True)
-    # backward
-    w_hhT = [tt(p[f"g.weight_hh_l{l}"].T, dt) for l in range(NL)]
-    w_ihT = [None] + [tt(p[f"g.weight_ih_l{l}"].T, dt) for l in range(1, NL)]
-    dG = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
-    dGT = [torch.zeros(G4, ldT, device=dev, dtype=dt) for _ in range(NL)]
-    dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
-    tdy = tt(dy)
-    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, w_hhT, [G4] * NL, w_ihT, [G4] * NL, tdy, H, hs, H, cs, gates, dG, dGT, ldT, dstate)
-    torch.cuda.synchronize()
-    # oracle dpre per layer: recompute from lstm_layer_bwd internals via dw identities
-    # compare weight grads computed the product way
-    for l in range(NL):
-        dwhh = torch.zeros(G4, H, device=dev)
-        ops.gemm_nt(dGT[l][:, B:], hsT[l], dwhh, G4, H, T * B - B, lda=ldT, ldb=ldT)
-        db = torch.zeros(G4, device=dev)
-        ops.rowsum(dGT[l], G4, T * B, db)
-        e1 = rel(dwhh.cpu().numpy(), grads[f"g.weight_hh_l{l}"]); e2 = rel(db.cpu().numpy(), grads[f"g.bias_ih_l{l}"])
-        msg = f"  bwd layer {l}: dW_hh rel={e1:.3e} db rel={e2:.3e}"
-        if l > 0:
-            dwih = torch.zeros(G4, H, device=dev)
-            ops.gemm_nt(dGT[l], hsT[l - 1], dwih, G4, H, T * B, lda=ldT, ldb=ldT)
-            msg += f" dW_ih rel={rel(dwih.cpu().numpy(), grads[f'g.weight_ih_l{l}']):.3e}"
-        else:
-            dx_h = dG[0].float().cpu().numpy().reshape(T * B, G4) @ p["g.weight_ih_l0"]
-            msg += f" dx rel={rel(dx_h.reshape(T, B, In), dx):.3e}"
-        chk = rel(dGT[l][:, :T * B].float().cpu().numpy(), dG[l].float().cpu().numpy().reshape(T * B, G4).T)
-        msg += f" dGT-vs-dG={chk:.1e} {'OK' if max(e1, e2) < tol else 'FAIL'}"
-        print(msg, flush=True)
+    import test_gpu_parity as tp
+    errs = tp._lstm_case(dt, T, B, H, NL, In)
+    for k, v in errs.items():
+        print(f"  {k}: rel={v:.3e} {'OK' if v < tol else 'FAIL'}")
 
 
 def t_small_ops():

@@ -67,43 +67,60 @@ def _lstm_case(dt, T, B, H, NL, In, seed=2):
     grads = {}
     dx = O.lstm_bwd(dy, caches, grads, "g")
     gx0 = t((x.reshape(T * B, In) @ p["g.weight_ih_l0"].T + p["g.bias_ih_l0"] + p["g.bias_hh_l0"]).reshape(T, B, G4))
-    ldT = (T * B + 7) // 8 * 8 + 8
     ldh, ldg = H + 8, G4 + 8
     hs = [torch.zeros(T, B, ldh, device=dev, dtype=dt) for _ in range(NL)]
-    hsT = [torch.zeros(H, ldT, device=dev, dtype=dt) for _ in range(NL)]
-    cs = [torch.zeros(T, B, H, device=dev) for _ in range(NL)]
+    cs = [torch.zeros(T, B, H, device=dev, dtype=dt) for _ in range(NL)]
+    cstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
     gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
     w_ih = [None] + [t(p[f"g.weight_ih_l{l}"], dt) for l in range(1, NL)]
     w_hh = [t(p[f"g.weight_hh_l{l}"], dt) for l in range(NL)]
     bias = [None] + [t(p[f"g.bias_ih_l{l}"] + p[f"g.bias_hh_l{l}"]) for l in range(1, NL)]
-    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, B * G4, w_ih, [H] * NL, w_hh, [H] * NL, bias, hs, ldh, hsT, ldT, cs, gates)
+    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, B * G4, w_ih, [H] * NL, w_hh, [H] * NL, bias, hs, ldh, cs, gates, cstate)
     w_hhT = [t(p[f"g.weight_hh_l{l}"].T, dt) for l in range(NL)]
     w_ihT = [None] + [t(p[f"g.weight_ih_l{l}"].T, dt) for l in range(1, NL)]
     dG = [torch.zeros(T, B, ldg, device=dev, dtype=dt) for _ in range(NL)]
-    dGT = [torch.zeros(G4, ldT, device=dev, dtype=dt) for _ in range(NL)]
     dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
-    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, w_hhT, [G4] * NL, w_ihT, [G4] * NL, t(dy), H, hs, ldh, cs, gates, dG, dGT, ldT, dstate, ldg=ldg)
+    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, w_hhT, [G4] * NL, w_ihT, [G4] * NL, t(dy), H, hs, ldh, cs, gates, dG, dstate, ldg=ldg)
     torch.cuda.synchronize()
     errs = {}
     for l in range(NL):
-        errs[f"h{l}"] = rel(hs[l][:, :, :H].float().cpu().numpy(), caches[l][1])
-        errs[f"c{l}"] = rel(cs[l].cpu().numpy(), caches[l][2])
-        errs[f"hT{l}"] = rel(hsT[l][:, :T * B].float().cpu().numpy(), caches[l][1].reshape(T * B, H).T)
-        assert float(hs[l][:, :, H:].abs().sum()) == 0.0          # pad columns stay zero
-        dwhh = torch.zeros(G4, H, device=dev)
-        ops.gemm_nt(dGT[l][:, B:], hsT[l], dwhh, G4, H, T * B - B, lda=ldT, ldb=ldT)
-        errs[f"dWhh{l}"] = rel(dwhh.cpu().numpy(), grads[f"g.weight_hh_l{l}"])
-        db = torch.zeros(G4, device=dev)
-        ops.rowsum(dGT[l], G4, T * B, db)
-        errs[f"db{l}"] = rel(db.cpu().numpy(), grads[f"g.bias_ih_l{l}"])
+        h_np = hs[l][:, :, :H].double().cpu().numpy()
+        errs[f"h{l}"] = rel(h_np, caches[l][1])
+        errs[f"c{l}"] = rel(cs[l].double().cpu().numpy(), caches[l][2])
+        errs[f"gates{l}"] = rel(gates[l].double().cpu().numpy(), caches[l][3])
+        assert float(hs[l][:, :, H:].abs().sum()) == 0.0 and float(dG[l][:, :, G4:].abs().sum()) == 0.0   # pads stay zero
+        dp = dG[l][:, :, :G4].double().cpu().numpy().reshape(T * B, G4)
+        hprev = np.concatenate([np.zeros((1, B, H)), h_np[:-1]], 0).reshape(T * B, H)
+        errs[f"dWhh{l}"] = rel(dp.T @ hprev, grads[f"g.weight_hh_l{l}"]) if T > 1 else 0.0
+        errs[f"db{l}"] = rel(dp.sum(0), grads[f"g.bias_ih_l{l}"])
         if l > 0:
-            dwih = torch.zeros(G4, H, device=dev)
-            ops.gemm_nt(dGT[l], hsT[l - 1], dwih, G4, H, T * B, lda=ldT, ldb=ldT)
-            errs[f"dWih{l}"] = rel(dwih.cpu().numpy(), grads[f"g.weight_ih_l{l}"])
-        assert torch.equal(dGT[l][:, :T * B], dG[l][:, :, :G4].reshape(T * B, G4).t())
+            xin = hs[l - 1][:, :, :H].double().cpu().numpy().reshape(T * B, H)
+            errs[f"dWih{l}"] = rel(dp.T @ xin, grads[f"g.weight_ih_l{l}"])
+        if dt == torch.bfloat16 and T > 1:        # the product path: hardware-transposed TN GEMM + vectorised column sum
+            dwhh = torch.zeros(G4, H, device=dev)
+            ops.gemm_tn(dG[l].view(T * B, ldg)[B:], hs[l].view(T * B, ldh), dwhh, G4, H, T * B - B, lda=ldg, ldb=ldh)
+            errs[f"tn_dWhh{l}"] = rel(dwhh.cpu().numpy(), dp.T @ hprev) * 10     # vs the same bf16 inputs: fp32 accumulate only
+            db = torch.zeros(G4, device=dev)
+            ops.colsum_t(dG[l].view(T * B, ldg), T * B, G4, db, ldx=ldg)
+            errs[f"tn_db{l}"] = rel(db.cpu().numpy(), dp.sum(0)) * 10
     dx_h = dG[0][:, :, :G4].float().cpu().numpy().reshape(T * B, G4) @ p["g.weight_ih_l0"]
     errs["dx"] = rel(dx_h.reshape(T, B, In), dx)
     return errs
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 64), (4096, 1024, 1024), (35, 1024, 4000), (300, 200, 513), (288, 72, 7), (130, 64, 61440 // 4)])
+def test_gemm_tn_bf16(shape):
+    """C = A^T . B from K-major bf16 operands (ds_read_b64_tr_b16 fragments): ragged M/N/K, split-K, over-read rows."""
+    M, N, K = shape
+    rs = np.random.RandomState(M + N + K)
+    lda, ldb = (M + 7) // 8 * 8 + 8, (N + 7) // 8 * 8 + 16
+    A = torch.zeros(K, lda, device=dev, dtype=torch.bfloat16); B = torch.zeros(K, ldb, device=dev, dtype=torch.bfloat16)
+    A[:, :M] = t(rs.standard_normal((K, M)), torch.bfloat16); B[:, :N] = t(rs.standard_normal((K, N)), torch.bfloat16)
+    A[:, M:] = 3.0; B[:, N:] = -2.0                      # pads must not leak into the result
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_tn(A, B, out, M, N, K, lda=lda, ldb=ldb)
+    ref = A[:, :M].double().cpu().numpy().T @ B[:, :N].double().cpu().numpy()
+    assert rel(out.cpu().numpy(), ref) < 2e-6
 
 
 @pytest.mark.parametrize("case", [
