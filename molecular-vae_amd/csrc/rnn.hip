@@ -165,10 +165,10 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   T* gout = reinterpret_cast<T*>(q.g_out);
   T* csave = reinterpret_cast<T*>(q.c_save);
 #pragma unroll
-  for (int it = 0; it < BM * 4 / 256; ++it) {
+  for (int it = 0; it < (BM * 4 + 255) / 256; ++it) {
     const int lrow = (tid >> 2) + it * 64;
     const int row = m0 + lrow;
-    if (row >= B) continue;
+    if (lrow >= BM || row >= B) continue;
     float pre[4][8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -302,10 +302,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
   const T* csp = reinterpret_cast<const T*>(q.c_prev);
   T* dG = reinterpret_cast<T*>(q.dG);
 #pragma unroll
-  for (int it = 0; it < BM * GPR / 256; ++it) {
+  for (int it = 0; it < (BM * GPR + 255) / 256; ++it) {
     const int lrow = tid / GPR + it * (256 / GPR);
     const int row = m0 + lrow;
-    if (row >= B) continue;
+    if (lrow >= BM || row >= B) continue;
     float dh[8];
     {
       const float* s = stg + lrow * SN + g8 * 8;
@@ -387,7 +387,13 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (d->x0 && (!d->w_ih[0] || d->in0 < 1)) return MVAE_ERR_INVALID;
   if (!d->x0 && !d->add0) return MVAE_ERR_INVALID;
   if (d->ldh % epc) return MVAE_ERR_INVALID;
-  const int BM = tune_int("MVAE_BM", (B > 64 && ((B + 127) / 128) * ((H + 31) / 32) * NL >= 256) ? 128 : 64);
+  // row tile: the largest of 128 / 64 / 32 that still gives >= 256 workgroups per launch (the f32 MFMA rate is 1/16 of bf16, so
+  // f32 stacks prefer many small tiles); MVAE_BM overrides
+  auto nblk = [&](int bm) { return (long)((B + bm - 1) / bm) * ((H + 31) / 32) * NL; };
+  int BM = (nblk(128) >= 256) ? 128 : (nblk(64) >= 256 || dt == MVAE_BF16) ? 64 : 32;
+  if (dt == MVAE_BF16) BM = 64;     // measured (B=512, H=1024): 64-row tiles with a 3-deep ring keep two workgroups per CU -> 53 vs 64 us/launch
+  BM = tune_int("MVAE_BM", BM);
+  if (BM == 32 && dt == MVAE_BF16) BM = 64;
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
   // deep-pipelined LDS-direct main loop: whole K-steps, 16-byte aligned rows, operands < 2 GiB
   bool pipe = (H % ke == 0) && (d->ldh % (16 / sz) == 0) && ((long)B * d->ldh * sz < (1L << 31)) && (!d->x0 || (d->in0 % ke == 0 && d->x0_ld % (16 / sz) == 0)) &&
@@ -402,7 +408,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   StepArgsF a;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + 31) / 32; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
-  const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", 4) : 0;
+  const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
   size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 128) * KB;
   const size_t stage_bytes = (size_t)BM * 4 * (32 + 4) * sizeof(float);     // epilogue staging tile
   if (lds < stage_bytes) lds = stage_bytes;
@@ -439,7 +445,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       FWD_CASE(bf16_t, 128, 0) FWD_CASE(bf16_t, 128, 3) FWD_CASE(bf16_t, 128, 4) FWD_CASE(bf16_t, 128, 5)
       FWD_CASE(bf16_t, 64, 0) FWD_CASE(bf16_t, 64, 3) FWD_CASE(bf16_t, 64, 4) FWD_CASE(bf16_t, 64, 5)
     } else {
-      FWD_CASE(float, 128, 0) FWD_CASE(float, 128, 4) FWD_CASE(float, 64, 0) FWD_CASE(float, 64, 4)
+      FWD_CASE(float, 128, 0) FWD_CASE(float, 128, 4) FWD_CASE(float, 64, 0) FWD_CASE(float, 64, 4) FWD_CASE(float, 32, 0) FWD_CASE(float, 32, 4)
     }
 #undef FWD_CASE
     return MVAE_ERR_UNSUPPORTED;
@@ -463,7 +469,13 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   }
   const long ldg = d->ldg;
   if (ldg < 4L * H || ldg % epc) return MVAE_ERR_INVALID;
-  const int BM = tune_int("MVAE_BM", (B > 64 && ((B + 127) / 128) * ((H + 63) / 64) * NL >= 200) ? 128 : 64);
+  // bf16: 64-row tiles (two workgroups per CU: one's epilogue runs under the other's main loop); f32: 32 x 32 tiles when the
+  // stack is small (MFMA-f32 bound per workgroup).  MVAE_BM overrides.
+  int BM = 64, BN = 64;
+  if (dt == MVAE_F32 && (long)((B + 63) / 64) * ((H + 63) / 64) * NL < 256) { BM = 32; BN = 32; }
+  BM = tune_int("MVAE_BM", BM);
+  if (BM == 32 && dt == MVAE_BF16) BM = 64;
+  if (BM != 32) BN = 64;
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
   bool pipe = ((4 * H) % ke == 0) && ((long)B * ldg * sz < (1L << 31)) && (ldg % (16 / sz) == 0);
   bool vec = (H % 8 == 0) && (ldg % 8 == 0) && al16(d->dy) && (d->dy_ld % 4 == 0);
@@ -473,11 +485,11 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     if (!al16(d->cs[l]) || !al16(d->gates[l]) || !al16(d->dG[l]) || !al16(d->dstate[l])) vec = false;
   }
   StepArgsB a;
-  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + 63) / 64; a.vec = vec ? 1 : 0;
+  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
   const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
-  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 64) * KB;
-  const size_t stage_bytes = (size_t)BM * (64 + 4) * sizeof(float);
+  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + BN) * KB;
+  const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   for (int e = T + NL - 2; e >= 0; --e) {
     int n = 0;
@@ -499,12 +511,12 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n), block(256);
-#define BWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<TT_, BM_, 64, NB_>)); continue; }
+#define BWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<TT_, BM_, (BM_ == 32 ? 32 : 64), NB_>)); continue; }
     if (dt == MVAE_BF16) {
       BWD_CASE(bf16_t, 128, 0) BWD_CASE(bf16_t, 128, 3) BWD_CASE(bf16_t, 128, 4) BWD_CASE(bf16_t, 128, 5) BWD_CASE(bf16_t, 128, 6)
       BWD_CASE(bf16_t, 64, 0) BWD_CASE(bf16_t, 64, 3) BWD_CASE(bf16_t, 64, 4) BWD_CASE(bf16_t, 64, 5) BWD_CASE(bf16_t, 64, 6)
     } else {
-      BWD_CASE(float, 128, 0) BWD_CASE(float, 128, 4) BWD_CASE(float, 64, 0) BWD_CASE(float, 64, 4)
+      BWD_CASE(float, 128, 0) BWD_CASE(float, 128, 4) BWD_CASE(float, 64, 0) BWD_CASE(float, 64, 4) BWD_CASE(float, 32, 0) BWD_CASE(float, 32, 4)
     }
 #undef BWD_CASE
     return MVAE_ERR_UNSUPPORTED;
