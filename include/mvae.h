@@ -125,6 +125,8 @@ typedef struct {
   void* cs[MVAE_MAX_LAYERS];
   void* gates[MVAE_MAX_LAYERS];
   float* cstate[MVAE_MAX_LAYERS];
+  int zero_padded_k;   /* != 0: rows of hs, h0, w_ih (l>0) and w_hh are allocated AND zero up to the next multiple of 128 bytes
+                          past H, so the contraction may run over whole K-steps (enables the LDS-direct main loop for e.g. H = 72) */
 } mvae_rnn_fwd_desc;
 
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);

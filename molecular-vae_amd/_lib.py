@@ -29,7 +29,8 @@ class RnnFwdDesc(C.Structure):
                 ("hs", _vp * MAX_LAYERS), ("ldh", _i64),
                 ("cs", _vp * MAX_LAYERS),
                 ("gates", _vp * MAX_LAYERS),
-                ("cstate", _vp * MAX_LAYERS)]
+                ("cstate", _vp * MAX_LAYERS),
+                ("zero_padded_k", _i)]
 
 
 class RnnBwdDesc(C.Structure):

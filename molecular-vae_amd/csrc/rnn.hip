@@ -395,8 +395,16 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   BM = tune_int("MVAE_BM", BM);
   if (BM == 32 && dt == MVAE_BF16) BM = 64;
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
+  // contraction length over the hidden axis: H, or H rounded up to whole K-steps when the caller guarantees zero padding
+  int Hk = H;
+  if (d->zero_padded_k && H % ke) {
+    const int hp = (H + ke - 1) / ke * ke;
+    bool ok = d->ldh >= hp && (!d->h0[0] || d->ldh0 >= hp);
+    for (int l = 0; l < NL; ++l) ok = ok && d->ldw_hh[l] >= hp && (l == 0 || d->ldw_ih[l] >= hp);
+    if (ok) Hk = hp;
+  }
   // deep-pipelined LDS-direct main loop: whole K-steps, 16-byte aligned rows, operands < 2 GiB
-  bool pipe = (H % ke == 0) && (d->ldh % (16 / sz) == 0) && ((long)B * d->ldh * sz < (1L << 31)) && (!d->x0 || (d->in0 % ke == 0 && d->x0_ld % (16 / sz) == 0)) &&
+  bool pipe = (Hk % ke == 0) && (d->ldh % (16 / sz) == 0) && ((long)B * d->ldh * sz < (1L << 31)) && (!d->x0 || (d->in0 % ke == 0 && d->x0_ld % (16 / sz) == 0)) &&
               (!d->h0[0] || d->ldh0 % (16 / sz) == 0);
   // 16-byte vector epilogue: 8-unit groups aligned in every array it touches
   bool vec = (H % 8 == 0) && (d->ldh % 8 == 0) && (!d->add0 || (al16(d->add0) && d->add0_tstride % 4 == 0));
@@ -425,12 +433,12 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
         q.add_ld = 4L * H;
       } else {
         q.A0 = adv(d->hs[l - 1], (long)t * B * d->ldh, dt);
-        q.lda0 = d->ldh; q.K0 = H; q.W0 = d->w_ih[l]; q.ldw0 = d->ldw_ih[l];
+        q.lda0 = d->ldh; q.K0 = Hk; q.W0 = d->w_ih[l]; q.ldw0 = d->ldw_ih[l];
         q.add = nullptr; q.add_ld = 0;
       }
       q.A1 = (t > 0) ? adv(d->hs[l], (long)(t - 1) * B * d->ldh, dt) : d->h0[l];
       q.lda1 = (t > 0) ? d->ldh : d->ldh0;
-      q.K1 = H; q.W1 = d->w_hh[l]; q.ldw1 = d->ldw_hh[l];
+      q.K1 = Hk; q.W1 = d->w_hh[l]; q.ldw1 = d->ldw_hh[l];
       q.bias = d->bias[l];
       q.c_prev = (t > 0) ? d->cstate[l] + (long)((t - 1) & 1) * B * H : nullptr;
       q.c_out = d->cstate[l] + (long)(t & 1) * B * H;

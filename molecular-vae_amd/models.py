@@ -14,6 +14,7 @@ Differences that are deliberate and documented:
     The encoder always runs in f32 (mu / logvar parity).
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -259,17 +260,22 @@ class MolEncoder(nn.Module):
             ops.cast_transpose(g.weight_ih_l0, 4 * H, E, dst=P["Wih0_p"], dstT=P["Wih0T"])
             P["bias"] = []
             P["WihT"], P["WhhT"] = [None], []
+            Hp = _pad(H, 32)                       # whole 128-byte K-steps (f32): zero-padded shadows -> LDS-direct main loop
+            P["Hp"] = Hp
+            P["Wih"], P["Whh"] = [None], []
             for l in range(NL):
                 b = ws.get(f"bias{l}", (4 * H,), torch.float32, dev)
                 torch.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), out=b)
                 P["bias"].append(b)
+                w = ws.get(f"Whh{l}", (4 * H, Hp), torch.float32, dev)
                 t = ws.get(f"WhhT{l}", (H, 4 * H), torch.float32, dev)
-                ops.cast_transpose(getattr(g, f"weight_hh_l{l}"), 4 * H, H, dstT=t)
-                P["WhhT"].append(t)
+                ops.cast_transpose(getattr(g, f"weight_hh_l{l}"), 4 * H, H, dst=w, dstT=t)
+                P["Whh"].append(w); P["WhhT"].append(t)
                 if l > 0:
+                    w = ws.get(f"Wih{l}", (4 * H, Hp), torch.float32, dev)
                     t = ws.get(f"WihT{l}", (H, 4 * H), torch.float32, dev)
-                    ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), 4 * H, H, dstT=t)
-                    P["WihT"].append(t)
+                    ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), 4 * H, H, dst=w, dstT=t)
+                    P["Wih"].append(w); P["WihT"].append(t)
             for n, conv in (("c1", self.conv_1[0]), ("c2", self.conv_2[0]), ("c3", self.conv_3[0])):
                 K = conv.in_channels * conv.kernel_size
                 t = ws.get(n + "_wT", (K, conv.out_channels), torch.float32, dev)
@@ -314,20 +320,19 @@ class _EncoderFn(torch.autograd.Function):
         gx0 = ws.get("gx0", (Lq, B, G4), f32, dev)
         ops.gather_rows_tb(idx, tbl, gx0, B, Lq, Cv, G4)
         # K2: 3-layer LSTM, f32 MFMA
-        hs = [ws.get(f"hs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
+        Hp = P["Hp"]
+        hs = [ws.get(f"hs{l}", (Lq, B, Hp), f32, dev) for l in range(NL)]      # rows zero-padded to whole K-steps
         cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
         gates = [ws.get(f"gates{l}", (Lq, B, G4), f32, dev) for l in range(NL)]
         cstate = [ws.get(f"cstate{l}", (2, B, H), f32, dev) for l in range(NL)]
-        w_ih = [None] + [getattr(g, f"weight_ih_l{l}") for l in range(1, NL)]
-        w_hh = [getattr(g, f"weight_hh_l{l}") for l in range(NL)]
-        ops.rnn_fwd(L.CELL_LSTM, f32, Lq, B, H, gx0, B * G4, w_ih, [H] * NL, w_hh, [H] * NL, [None] + P["bias"][1:],
-                    hs, H, cs, gates, cstate, tag="enc_lstm_fwd")
+        ops.rnn_fwd(L.CELL_LSTM, f32, Lq, B, H, gx0, B * G4, P["Wih"], [Hp] * NL, P["Whh"], [Hp] * NL, [None] + P["bias"][1:],
+                    hs, Hp, cs, gates, cstate, zero_padded_k=True, tag="enc_lstm_fwd")
         # K3: conv stack over the hidden axis, sequence position = channel (models.py:129-131)
         c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
         k = c1.kernel_size
         W1, W2, W3 = H - k + 1, H - 2 * k + 2, H - 3 * k + 3
         col1 = ws.get("col1", (B * W1, Lq * k), f32, dev); y1 = ws.get("y1", (B * W1, c1.out_channels), f32, dev)
-        ops.conv1d_selu_fwd(hs[-1], (H, B * H, 1), B, Lq, H, c1.out_channels, k, c1.weight, c1.bias, col1, y1)
+        ops.conv1d_selu_fwd(hs[-1], (Hp, B * Hp, 1), B, Lq, H, c1.out_channels, k, c1.weight, c1.bias, col1, y1)
         col2 = ws.get("col2", (B * W2, c2.in_channels * k), f32, dev); y2 = ws.get("y2", (B * W2, c2.out_channels), f32, dev)
         ops.conv1d_selu_fwd(y1, (W1 * c1.out_channels, 1, c1.out_channels), B, c2.in_channels, W1, c2.out_channels, k,
                             c2.weight, c2.bias, col2, y2)
@@ -418,14 +423,15 @@ class _EncoderFn(torch.autograd.Function):
         ops.conv1d_selu_bwd(B, Lq, H, c1.out_channels, k, dy1, y1, col1, P["c1_wT"], c1.out_channels,
                             grads["conv_1.0.weight"], grads["conv_1.0.bias"], dhs, (H, B * H, 1))
         # K2 backward (reverse wavefront) + weight gradients
-        hs = [W(f"hs{l}", (Lq, B, H)) for l in range(NL)]
+        Hp = P["Hp"]
+        hs = [W(f"hs{l}", (Lq, B, Hp)) for l in range(NL)]
         cs = [W(f"cs{l}", (Lq, B, H)) for l in range(NL)]
         gates = [W(f"gates{l}", (Lq, B, G4)) for l in range(NL)]
         dG = [W(f"dG{l}", (Lq, B, G4)) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
-        ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, H, cs, gates,
+        ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, Hp, cs, gates,
                     dG, dstate, tag="enc_lstm_bwd")
-        _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, H)
+        _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp)
         # K1 backward: table gradient, then embedding / W_ih0
         dtbl = W("dtbl", (Cv, G4))
         ops.scatter_rows_tb(idx, dG[0], dtbl, B, Lq, Cv, G4)
@@ -434,6 +440,7 @@ class _EncoderFn(torch.autograd.Function):
         dtblT = W("dtblT", (G4, Cp))
         ops.cast_transpose(dtbl, Cv, G4, dstT=dtblT)
         ops.gemm_nt(dtblT, P["ET"], grads["gru.weight_ih_l0"], G4, E, Cp)
+        ops.join_pending()        # the decoder's weight-gradient GEMMs that ran on the side stream under this backward
         return (None, None, None) + tuple(grads[n] for n in names)
 
 
@@ -451,6 +458,14 @@ class MolDecoder(nn.Module):
         self._ws = _Workspace()
         self._pack_key = None
         self._packed = {}
+        self.__dict__["_peer"] = None          # weakref to the encoder whose backward runs after ours (set by MolecularVAE)
+        self.__dict__["_side"] = None
+        self.overlap_weight_grads = True       # run the weight-gradient GEMMs on a side stream under the encoder's backward
+
+    def _side_stream(self, dev):
+        if self.__dict__["_side"] is None:
+            self.__dict__["_side"] = torch.cuda.Stream(device=dev)
+        return self.__dict__["_side"]
 
     def forward(self, x):
         return _DecoderFn.apply(self, x, *list(self.parameters()))
@@ -568,19 +583,11 @@ class _DecoderFn(torch.autograd.Function):
         gates = [W(f"gates{l}", (Lq, B, G4), dt) for l in range(NL)]
         # K8 backward
         dl = W("dl", (TB + 8, Cp), dt)[:TB]      # +8 rows: the TN tile reads 256-byte row segments past the last row
-        if dt == torch.bfloat16:
-            ops.softmax_tb_bwd(recon, drecon, dl, None, B, Lq, Cv)
-            ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=Cp, ldb=ldh)
-            dbp = W("dbout_p", (Cp,))
-            ops.colsum_t(dl, TB, Cp, dbp, ldx=Cp)
-            grads["decoded_mean.module.0.bias"].copy_(dbp[:Cv])
-        else:
+        dlT = None
+        if dt != torch.bfloat16:
             ldT = _pad(TB, 8) + 8
-            dlT = W("dlT", (Cv, ldT), dt); hsT = W("wg_hsT_out", (H, ldT), dt)
-            ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
-            ops.cast_transpose(hs[-1].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
-            ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
-            ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
+            dlT = W("dlT", (Cv, ldT), dt)
+        ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
         dy = W("dy", (TB, H))
         ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
         # K7 backward
@@ -588,8 +595,38 @@ class _DecoderFn(torch.autograd.Function):
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [P["ldwT"]] * NL, P["WihT"], [P["ldwT"]] * NL, dy, H, hs, ldh, cs, gates,
                     dG, dstate, ldg=ldg, tag="dec_lstm_bwd")
-        with ops._Timed("dec_lstm_wgrad"):
-            _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh)
+
+        def weight_grads():
+            """Everything that only produces parameter gradients (nothing on the path to dz): output head + LSTM weights."""
+            with ops._Timed("dec_lstm_wgrad"):
+                if dt == torch.bfloat16:
+                    ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=Cp, ldb=ldh)
+                    dbp = W("dbout_p", (Cp,))
+                    ops.colsum_t(dl, TB, Cp, dbp, ldx=Cp)
+                    grads["decoded_mean.module.0.bias"].copy_(dbp[:Cv])
+                else:
+                    hsT = W("wg_hsT_out", (H, ldT), dt)
+                    ops.cast_transpose(hs[-1].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
+                    ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
+                    ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
+                _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh)
+
+        # Fork: the weight-gradient GEMMs are throughput-bound and independent of dz, while the encoder's backward that follows is a
+        # latency-bound chain of small launches -> run them concurrently.  Only when our MolecularVAE peer will join the side stream
+        # (its backward ends with ops.join_pending) and no gradient accumulation is pending (p.grad is assigned, never added to).
+        peer = mod.__dict__["_peer"]() if mod.__dict__["_peer"] is not None else None
+        fork = bool(mod.overlap_weight_grads and peer is not None and ctx.needs_input_grad[1] and all(p.grad is None for p in params))
+        if fork:
+            e1 = torch.cuda.Event(); e1.record()
+            side = mod._side_stream(dev)
+            side.wait_event(e1)
+            gflat.record_stream(side)
+            with torch.cuda.stream(side):
+                weight_grads()
+                e2 = torch.cuda.Event(); e2.record()
+            ops.PENDING.append(e2)
+        else:
+            weight_grads()
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
         dgx0 = W("dgx0", (B, ldg))           # pad columns of dG are zero, so the padded time sum is too
         ops.timesum(dG[0], Lq, B, ldg, dgx0)
@@ -607,6 +644,11 @@ class _DecoderFn(torch.autograd.Function):
         ops.colsum(dli, B, o, grads["latent_input.0.bias"])
         dz = torch.empty(B, o, dtype=f32, device=dev)
         ops.gemm_nt(dli, P["WliT"], dz, B, o, o, ldb=P["WliT"].stride(0))
+        if fork:
+            # gradients are still being written on the side stream: hand them over by assignment (autograd must not touch them)
+            for n, p in zip(names, params):
+                p.grad = grads[n]
+            return (None, dz) + (None,) * len(names)
         return (None, dz) + tuple(grads[n] for n in names)
 
 
@@ -618,6 +660,7 @@ class MolecularVAE(nn.Module):
         super().__init__()
         self.encoder = MolEncoder(i=i, o=o, c=c)
         self.decoder = MolDecoder(i=o, o=i, c=c, dtype=dtype)
+        self.decoder.__dict__["_peer"] = weakref.ref(self.encoder)
 
     def forward(self, x, eps=None):
         x, mu, logvar = self.encoder(x, eps) if eps is not None else self.encoder(x)

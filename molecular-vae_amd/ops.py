@@ -36,13 +36,24 @@ class _Timed:
         return False
 
 
+# events of work forked onto a side stream that nobody has joined yet (joined by the encoder's backward / FusedAdam.step)
+PENDING = []
+
+
+def join_pending():
+    """Make the current stream wait for every forked piece of work (weight-gradient GEMMs on the side stream)."""
+    while PENDING:
+        torch.cuda.current_stream().wait_event(PENDING.pop())
+
+
 class Scratch:
-    """Grow-only byte scratch for split-K slabs and op-internal temporaries (one per device)."""
+    """Grow-only byte scratch for split-K slabs and op-internal temporaries (one per device AND stream: two streams must
+    never share split-K slabs)."""
     _bufs = {}
 
     @classmethod
     def get(cls, nbytes, device):
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
         b = cls._bufs.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -188,7 +199,7 @@ def _fill(arr, tensors):
 
 
 def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, cs, gates, cstate,
-            x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, tag=None):
+            x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, zero_padded_k=False, tag=None):
     d = L.RnnFwdDesc()
     NL = len(w_hh)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H, d.in0 = cell, dt_code(dtype), NL, T, B, H, in0
@@ -210,6 +221,7 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
     _fill(d.gates, gates)
     if cstate is not None:
         _fill(d.cstate, cstate)
+    d.zero_padded_k = 1 if zero_padded_k else 0
     with _Timed(tag):
         check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
 

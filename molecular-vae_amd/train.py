@@ -149,6 +149,7 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        ops.join_pending()             # gradients produced on a side stream (decoder weight-gradient GEMMs)
         flats = self.gather_grads()
         sync = self.grad_sync
         if sync is not None:

@@ -29,6 +29,8 @@ def build_modules(dims, params, dtype, dev="cuda"):
                          if k.startswith("encoder.")})
     dec.load_state_dict({k[len("decoder."):]: torch.from_numpy(np.asarray(v, np.float32)) for k, v in params.items()
                          if k.startswith("decoder.")})
+    import weakref
+    dec.__dict__["_peer"] = weakref.ref(enc)      # pair them as MolecularVAE does: exercises the side-stream weight-gradient fork
     return enc.to(dev), dec.to(dev)
 
 
