@@ -41,6 +41,7 @@ extern "C" {
 
 #define MVAE_ACT_NONE 0
 #define MVAE_ACT_SELU 1           /* models.py:58-68 */
+#define MVAE_ACT_RELU 2           /* mosesvae.py:66-67 */
 
 #define MVAE_CELL_LSTM 0          /* torch.nn.LSTM, gate rows [i;f;g;o]  (models.py:117,156) */
 #define MVAE_CELL_GRU 1           /* torch.nn.GRU,  gate rows [r;z;n]    (mosesvae.py:54-61,73-79) */
@@ -85,7 +86,8 @@ int mvae_permute021(int N, int A, int Bd, const float* in, float* out, void* str
 
 /* out[(t*B + b), :] = table[idx[b*L + t], :]   (fp32, W columns).  models.py:127 nn.Embedding, fused with the
  * layer-0 input projection: table = E . W_ih0^T + b. */
-int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float* table, int W, float* out, void* stream);
+int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float* table, int W, const float* base /* optional [B, W] per-sequence addend */,
+                        float* out, void* stream);
 /* dtable[c, :] = sum over (t,b) with idx[b*L+t]==c of d[(t*B+b), :]   (deterministic).  d has dtype `dtype`. */
 int mvae_scatter_rows_tb(int dtype, const int64_t* idx, int B, int L, int nrows, const void* d, int64_t ldd, int W,
                          float* dtable, void* ws, size_t ws_bytes, void* stream);
@@ -225,6 +227,26 @@ int mvae_bce_kl_loss_fwd(int64_t n_recon, const float* recon, const float* targe
 int mvae_bce_kl_loss_bwd(int64_t n_recon, const float* recon, const float* target, int64_t n_latent, const float* mu,
                          const float* logvar, float max_len, const float* grad_out, float* drecon, float* dmu,
                          float* dlogvar, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * MOSES GRU path (mosesvae.py:126-199).
+ *   mvae_moses_latent_*: z = mu + exp(logvar/2)*eps and kl = 0.5*mean_b sum_j(exp(logvar) + mu^2 - 1 - logvar)  (mosesvae.py:158-162);
+ *     backward adds dkl * d(kl) and an optional external dlogvar (logvar is a return value of VAE.forward).
+ *   mvae_ce_loss_*: F.cross_entropy(y[:, :-1], x[:, 1:], ignore_index=pad) (mosesvae.py:193-197) on TIME-MAJOR logits
+ *     (row t*B+b, leading dimension ldl); loss2[0] = loss, loss2[1] = number of counted tokens.  Backward writes dlogits in
+ *     `dtype` with zero-padded columns V..ldd-1 (the next GEMM's K), adding an optional external dy given in [B,T,V] layout.
+ *   mvae_permute102: [T,B,V] -> [B,T,V] (the `y` return value); mvae_relu_bwd: dy *= (y > 0) in place.
+ */
+int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* stream);
+int mvae_moses_latent_bwd(int B, int dz, const float* mu, const float* logvar, const float* eps, const float* dz_in, const float* dkl,
+                          const float* dlogvar_ext, float* dmu, float* dlogvar, void* stream);
+size_t mvae_ce_loss_workspace(int B, int T);
+int mvae_ce_loss_fwd(int B, int T, int V, const float* logits, int64_t ldl, const int64_t* x, int pad, float* loss2, void* ws, size_t ws_bytes,
+                     void* stream);
+int mvae_ce_loss_bwd(int dtype, int B, int T, int V, const float* logits, int64_t ldl, const int64_t* x, int pad, const float* loss2,
+                     const float* grad_out, const float* dy_ext, void* dl, int64_t ldd, void* stream);
+int mvae_permute102(int T, int B, int V, const float* in, float* out, void* stream);
+int mvae_relu_bwd(int64_t n, float* dy, const float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Optimiser surface (K14 + K15): torch.nn.utils.clip_grad_norm_(params, max_norm) (train.py:102) followed by

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvae_hip.so")
 
 MVAE_F32, MVAE_BF16 = 0, 1
-ACT_NONE, ACT_SELU = 0, 1
+ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
 CELL_LSTM, CELL_GRU = 0, 1
 MAX_LAYERS = 8
 
@@ -60,7 +60,7 @@ SIGNATURES = {
     "mvae_gemm_tn": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "mvae_cast_transpose": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "mvae_permute021": (_i, [_i, _i, _i, _vp, _vp, _vp]),
-    "mvae_gather_rows_tb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "mvae_gather_rows_tb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
@@ -84,6 +84,13 @@ SIGNATURES = {
     "mvae_bce_kl_loss_workspace": (_sz, [_i64, _i64]),
     "mvae_bce_kl_loss_fwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "mvae_bce_kl_loss_bwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_moses_latent_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_moses_latent_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_ce_loss_workspace": (_sz, [_i, _i]),
+    "mvae_ce_loss_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),
+    "mvae_ce_loss_bwd": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mvae_permute102": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "mvae_relu_bwd": (_i, [_i64, _vp, _vp, _vp]),
     "mvae_sumsq_workspace": (_sz, [_i64]),
     "mvae_sumsq": (_i, [_i64, _vp, _vp, _vp]),
     "mvae_clip_adam": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),

@@ -58,46 +58,55 @@ int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, lon
 }
 
 // ------------------------------------------------------------------------------------------- embedding table
-__global__ __launch_bounds__(256) void gather_rows_tb_kernel(const int64_t* idx, int B, int L, int nrows, const float* table, int W, float* out) {
+__global__ __launch_bounds__(256) void gather_rows_tb_kernel(const int64_t* idx, int B, int L, int nrows, const float* table, int W,
+                                                             const float* base, float* out) {
   const long n = (long)B * L * W;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long row = i / W; const int c = (int)(i - row * W);
     const int t = (int)(row / B), b = (int)(row - (long)t * B);
     long id = idx[(long)b * L + t];
     id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
-    out[i] = table[id * W + c];
+    out[i] = table[id * W + c] + (base ? base[(long)b * W + c] : 0.f);
   }
 }
 
-// stage 1: block k owns rows [k*RPB, (k+1)*RPB) of d; thread j owns column j; LDS table [nrows][W] (per-thread column => no races).
+// stage 1: block (k, s) owns rows [k*RPB, (k+1)*RPB) of d and the column slice [s*WS, (s+1)*WS); thread j owns one column of the slice;
+// LDS table [nrows][WS] (per-thread column => no races, fixed order => deterministic).
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_tb_stage1(const int64_t* idx, int B, int L, int nrows, const T* d, long ldd, int W,
-                                                              int rpb, float* partial) {
+                                                              int rpb, int ws_cols, float* partial) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* tab = reinterpret_cast<float*>(smem_raw);   // [nrows][W]
+  float* tab = reinterpret_cast<float*>(smem_raw);   // [nrows][ws_cols]
   const long total = (long)B * L;
-  for (int i = threadIdx.x; i < nrows * W; i += 256) tab[i] = 0.f;
+  const int c_lo = blockIdx.y * ws_cols;
+  int c_hi = c_lo + ws_cols; if (c_hi > W) c_hi = W;
+  const int wsl = c_hi - c_lo;
+  for (int i = threadIdx.x; i < nrows * ws_cols; i += 256) tab[i] = 0.f;
   __syncthreads();
   const long rbeg = (long)blockIdx.x * rpb;
   long rend = rbeg + rpb; if (rend > total) rend = total;
-  for (int c = threadIdx.x; c < W; c += 256) {
+  for (int c = threadIdx.x; c < wsl; c += 256) {
     for (long row = rbeg; row < rend; ++row) {
       const int t = (int)(row / B), b = (int)(row - (long)t * B);
       long id = idx[(long)b * L + t];
       id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
-      tab[id * W + c] += TT<T>::ld(d + row * ldd + c);
+      tab[id * ws_cols + c] += TT<T>::ld(d + row * ldd + c_lo + c);
     }
   }
   __syncthreads();
   float* out = partial + (long)blockIdx.x * nrows * W;
-  for (int i = threadIdx.x; i < nrows * W; i += 256) out[i] = tab[i];
+  for (int i = threadIdx.x; i < nrows * wsl; i += 256) { const int r = i / wsl, c = i - r * wsl; out[(long)r * W + c_lo + c] = tab[r * ws_cols + c]; }
 }
+// out[i] = sum_k partial[k][i]: 64 elements x 4 interleaved k-slots per block, fixed combination order (deterministic)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial, int nparts, long n, float* out) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float v = 0.f;
-    for (int k = 0; k < nparts; ++k) v += partial[(long)k * n + i];
-    out[i] = v;
-  }
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + e;
+  float v = 0.f;
+  if (i < n) for (int k = slot; k < nparts; k += 4) v += partial[(long)k * n + i];
+  red[slot][e] = v;
+  __syncthreads();
+  if (slot == 0 && i < n) out[i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // ------------------------------------------------------------------------------------------- im2col / col2im
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(int M, int N, const 
   __syncthreads();
   if (g == 0 && c < N) partial[(long)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-static int colsum_chunks(int M) { int c = (M + 511) / 512; if (c > 128) c = 128; if (c < 1) c = 1; return c; }
+static int colsum_chunks(int M) { int c = (M + 511) / 512; if (c > 48) c = 48; if (c < 1) c = 1; return c; }
 size_t colsum_workspace_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
 int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
   if (N <= 0) return MVAE_OK;
@@ -167,7 +176,7 @@ int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, 
   if (!ws || ws_bytes < colsum_workspace_bytes(M, N)) return MVAE_ERR_WORKSPACE;
   const int rpc = (M + chunks - 1) / chunks;
   hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, M, N, X, ldx, rpc, (float*)ws);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(grid_for(N)), dim3(256), 0, st, (const float*)ws, chunks, (long)N, out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, (const float*)ws, chunks, (long)N, out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(256) void colsum_t_stage1_kernel(int M, int N, cons
     partial[(long)blockIdx.y * N + c] = v;
   }
 }
-static int colsum_t_chunks(int M) { int c = (M + 255) / 256; if (c > 240) c = 240; if (c < 1) c = 1; return c; }
+static int colsum_t_chunks(int M) { int c = (M + 511) / 512; if (c > 64) c = 64; if (c < 1) c = 1; return c; }
 
 // out[r] (+)= sum_c X[r, c]: one wave per row, 16-byte loads when the row is 16-byte aligned
 template <typename T> __device__ __forceinline__ float sum_chunk16(const uint4& v);
@@ -398,6 +407,105 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, float* p, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------- MOSES path (mosesvae.py)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(long n, float* dy, const float* y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dy[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+// out[b, t, :] = in[t, b, :]
+__global__ __launch_bounds__(256) void permute102_kernel(int T_, int B, int V, const float* in, float* out) {
+  const long n = (long)T_ * B * V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % V); const long bt = i / V; const int t = (int)(bt % T_); const int b = (int)(bt / T_);
+    out[i] = in[((long)t * B + b) * V + v];
+  }
+}
+// z = mu + exp(logvar/2) * eps ; kl = 0.5 * mean_b sum_j (exp(logvar) + mu^2 - 1 - logvar)      (mosesvae.py:158-162)
+__global__ __launch_bounds__(256) void moses_latent_fwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z,
+                                                               float* kl_out) {
+  __shared__ float red[4];
+  const long n = (long)B * dz;
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) {            // single block: deterministic, B*dz is small (<= a few 1e5)
+    const float m = mu[i], lv = logvar[i];
+    z[i] = m + expf(lv * 0.5f) * eps[i];
+    a += expf(lv) + m * m - 1.f - lv;
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) kl_out[0] = 0.5f * a / (float)B;
+}
+__global__ __launch_bounds__(256) void moses_latent_bwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps,
+                                                               const float* dzv, const float* dkl, const float* dlogvar_ext, float* dmu, float* dlogvar) {
+  const long n = (long)B * dz;
+  const float g = dkl ? dkl[0] : 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float m = mu[i], lv = logvar[i], d = dzv ? dzv[i] : 0.f;
+    dmu[i] = d + g * m / (float)B;
+    dlogvar[i] = d * eps[i] * 0.5f * expf(lv * 0.5f) + g * 0.5f * (expf(lv) - 1.f) / (float)B + (dlogvar_ext ? dlogvar_ext[i] : 0.f);
+  }
+}
+// token cross-entropy of mosesvae.py:193-197: logits row (t*B+b) predicts x[b, t+1]; targets == pad are ignored; mean over the rest.
+// one wave per (t, b) row; partial[(row)] = nll or 0, cnt likewise; reduced in fixed order by the final kernel.
+__global__ __launch_bounds__(256) void ce_tb_fwd_kernel(int B, int T_, int V, const float* logits, long ldl, const int64_t* x, int pad,
+                                                        float* nll, float* cnt) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)B * T_) return;
+  const int t = (int)(row / B), b = (int)(row - (long)t * B);
+  float out = 0.f, c = 0.f;
+  if (t + 1 < T_) {
+    const long tgt = x[(long)b * T_ + t + 1];
+    if (tgt != pad) {
+      const float* l = logits + row * ldl;
+      float mx = -INFINITY;
+      for (int v = lane; v < V; v += 64) mx = fmaxf(mx, l[v]);
+      mx = wave_max(mx);
+      float s = 0.f;
+      for (int v = lane; v < V; v += 64) s += expf(l[v] - mx);
+      s = wave_sum(s);
+      out = mx + logf(s) - l[tgt];
+      c = 1.f;
+    }
+  }
+  if (lane == 0) { nll[row] = out; cnt[row] = c; }
+}
+__global__ __launch_bounds__(256) void ce_tb_final_kernel(long rows, const float* nll, const float* cnt, float* out2) {
+  __shared__ float red[4];
+  float a = 0.f, c = 0.f;
+  for (long i = threadIdx.x; i < rows; i += 256) { a += nll[i]; c += cnt[i]; }
+  a = block_sum_256(a, red);
+  c = block_sum_256(c, red);
+  if (threadIdx.x == 0) { out2[0] = a / c; out2[1] = c; }
+}
+// dlogits[(t*B+b), :] = g * (softmax - onehot(target)) / ntok for counted rows, 0 otherwise (+ optional external dy in [B,T,V] layout)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_tb_bwd_kernel(int B, int T_, int V, const float* logits, long ldl, const int64_t* x, int pad,
+                                                        const float* loss2, const float* g, const float* dy_ext, T* dl, long ldd) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)B * T_) return;
+  const int t = (int)(row / B), b = (int)(row - (long)t * B);
+  const float scale = (g ? g[0] : 1.f) / loss2[1];
+  bool on = false; long tgt = 0;
+  if (t + 1 < T_) { tgt = x[(long)b * T_ + t + 1]; on = tgt != pad; }
+  const float* l = logits + row * ldl;
+  float mx = -INFINITY, s = 1.f;
+  if (on) {
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, l[v]);
+    mx = wave_max(mx);
+    s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(l[v] - mx);
+    s = wave_sum(s);
+  }
+  for (int v = lane; v < ldd; v += 64) {
+    float d = 0.f;
+    if (v < V) {
+      if (on) d = scale * (expf(l[v] - mx) / s - (v == tgt ? 1.f : 0.f));
+      if (dy_ext) d += dy_ext[((long)b * T_ + t) * V + v];
+    }
+    TT<T>::st(dl + row * ldd + v, d);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- extern "C" surface
 extern "C" {
 
@@ -413,9 +521,9 @@ int mvae_permute021(int N, int A, int Bd, const float* in, float* out, void* str
   return MVAE_OK;
 }
 
-int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float* table, int W, float* out, void* stream) {
+int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float* table, int W, const float* base, float* out, void* stream) {
   if (!idx || !table || !out || B < 1 || L < 1 || W < 1 || nrows < 1) return MVAE_ERR_INVALID;
-  hipLaunchKernelGGL(gather_rows_tb_kernel, dim3(grid_for((long)B * L * W)), dim3(256), 0, (hipStream_t)stream, idx, B, L, nrows, table, W, out);
+  hipLaunchKernelGGL(gather_rows_tb_kernel, dim3(grid_for((long)B * L * W)), dim3(256), 0, (hipStream_t)stream, idx, B, L, nrows, table, W, base, out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
@@ -425,19 +533,22 @@ size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W) { return (
 int mvae_scatter_rows_tb(int dtype, const int64_t* idx, int B, int L, int nrows, const void* d, int64_t ldd, int W, float* dtable,
                          void* ws, size_t ws_bytes, void* stream) {
   if (!idx || !d || !dtable || B < 1 || L < 1 || W < 1 || nrows < 1) return MVAE_ERR_INVALID;
-  const size_t ldsb = (size_t)nrows * W * sizeof(float);
-  if (ldsb > 64 * 1024) return MVAE_ERR_UNSUPPORTED;
+  int ws_cols = (48 * 1024) / (nrows * (int)sizeof(float));        // column slice so that the LDS table stays <= 48 KiB
+  if (ws_cols < 1) return MVAE_ERR_UNSUPPORTED;
+  if (ws_cols > W) ws_cols = W;
+  const int slices = (W + ws_cols - 1) / ws_cols;
+  const size_t ldsb = (size_t)nrows * ws_cols * sizeof(float);
   const int parts = scatter_parts(B, L);
   if (!ws || ws_bytes < mvae_scatter_rows_tb_workspace(B, L, nrows, W)) return MVAE_ERR_WORKSPACE;
   const long rows = (long)B * L;
   const int rpb = (int)((rows + parts - 1) / parts);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MVAE_F32)
-    hipLaunchKernelGGL((scatter_rows_tb_stage1<float>), dim3(parts), dim3(256), ldsb, st, idx, B, L, nrows, (const float*)d, ldd, W, rpb, (float*)ws);
+    hipLaunchKernelGGL((scatter_rows_tb_stage1<float>), dim3(parts, slices), dim3(256), ldsb, st, idx, B, L, nrows, (const float*)d, ldd, W, rpb, ws_cols, (float*)ws);
   else if (dtype == MVAE_BF16)
-    hipLaunchKernelGGL((scatter_rows_tb_stage1<bf16_t>), dim3(parts), dim3(256), ldsb, st, idx, B, L, nrows, (const bf16_t*)d, ldd, W, rpb, (float*)ws);
+    hipLaunchKernelGGL((scatter_rows_tb_stage1<bf16_t>), dim3(parts, slices), dim3(256), ldsb, st, idx, B, L, nrows, (const bf16_t*)d, ldd, W, rpb, ws_cols, (float*)ws);
   else return MVAE_ERR_INVALID;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(grid_for((long)nrows * W)), dim3(256), 0, st, (const float*)ws, parts, (long)nrows * W, dtable);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)(((long)nrows * W + 63) / 64)), dim3(256), 0, st, (const float*)ws, parts, (long)nrows * W, dtable);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
@@ -473,7 +584,7 @@ int mvae_colsum_t(int dtype, int M, int N, const void* X, int64_t ldx, float* ou
   if (dtype == MVAE_F32) hipLaunchKernelGGL((colsum_t_stage1_kernel<float>), grid, dim3(256), 0, st, M, N, (const float*)X, ldx, rpc, (float*)ws);
   else if (dtype == MVAE_BF16) hipLaunchKernelGGL((colsum_t_stage1_kernel<bf16_t>), grid, dim3(256), 0, st, M, N, (const bf16_t*)X, ldx, rpc, (float*)ws);
   else return MVAE_ERR_INVALID;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(grid_for(N)), dim3(256), 0, st, (const float*)ws, chunks, (long)N, out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, (const float*)ws, chunks, (long)N, out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
@@ -481,6 +592,59 @@ size_t mvae_colsum_workspace(int M, int N) { return colsum_workspace_bytes(M, N)
 int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream) {
   if (!X || !out || M < 0) return MVAE_ERR_INVALID;
   return launch_colsum(M, N, X, ldx, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int mvae_relu_bwd(int64_t n, float* dy, const float* y, void* stream) {
+  if (!dy || !y) return MVAE_ERR_INVALID;
+  if (n <= 0) return MVAE_OK;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, dy, y);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_permute102(int T, int B, int V, const float* in, float* out, void* stream) {
+  if (!in || !out || T < 1 || B < 1 || V < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(permute102_kernel, dim3(grid_for((long)T * B * V)), dim3(256), 0, (hipStream_t)stream, T, B, V, in, out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* stream) {
+  if (!mu || !logvar || !eps || !z || !kl_out || B < 1 || dz < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(moses_latent_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, dz, mu, logvar, eps, z, kl_out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_moses_latent_bwd(int B, int dz, const float* mu, const float* logvar, const float* eps, const float* dzv, const float* dkl,
+                          const float* dlogvar_ext, float* dmu, float* dlogvar, void* stream) {
+  if (!mu || !logvar || !eps || !dmu || !dlogvar || B < 1 || dz < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(moses_latent_bwd_kernel, dim3(grid_for((long)B * dz)), dim3(256), 0, (hipStream_t)stream, B, dz, mu, logvar, eps, dzv, dkl,
+                     dlogvar_ext, dmu, dlogvar);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+size_t mvae_ce_loss_workspace(int B, int T) { return (size_t)B * T * 2 * sizeof(float); }
+int mvae_ce_loss_fwd(int B, int T, int V, const float* logits, int64_t ldl, const int64_t* x, int pad, float* loss2, void* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!logits || !x || !loss2 || B < 1 || T < 1 || V < 1) return MVAE_ERR_INVALID;
+  if (!ws || ws_bytes < mvae_ce_loss_workspace(B, T)) return MVAE_ERR_WORKSPACE;
+  const long rows = (long)B * T;
+  float* nll = (float*)ws; float* cnt = nll + rows;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_tb_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, B, T, V, logits, (long)ldl, x, pad, nll, cnt);
+  hipLaunchKernelGGL(ce_tb_final_kernel, dim3(1), dim3(256), 0, st, rows, (const float*)nll, (const float*)cnt, loss2);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_ce_loss_bwd(int dtype, int B, int T, int V, const float* logits, int64_t ldl, const int64_t* x, int pad, const float* loss2,
+                     const float* grad_out, const float* dy_ext, void* dl, int64_t ldd, void* stream) {
+  if (!logits || !x || !loss2 || !dl || B < 1 || T < 1 || V < 1 || ldd < V) return MVAE_ERR_INVALID;
+  const long rows = (long)B * T;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MVAE_F32)
+    hipLaunchKernelGGL((ce_tb_bwd_kernel<float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, B, T, V, logits, (long)ldl, x, pad, loss2, grad_out, dy_ext, (float*)dl, (long)ldd);
+  else if (dtype == MVAE_BF16)
+    hipLaunchKernelGGL((ce_tb_bwd_kernel<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, B, T, V, logits, (long)ldl, x, pad, loss2, grad_out, dy_ext, (bf16_t*)dl, (long)ldd);
+  else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
 }
 int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream) {
   if (!dy || !y) return MVAE_ERR_INVALID;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
           p.partial[((long)split * p.M + row) * p.N + col] = v;
         } else {
           if (p.bias) v += p.bias[col];
-          if (p.act == MVAE_ACT_SELU) v = selu_f(v);
+          if (p.act == MVAE_ACT_SELU) v = selu_f(v); else if (p.act == MVAE_ACT_RELU) v = fmaxf(v, 0.f);
           store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
         }
       }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
     float v = 0.f;
     for (int s = 0; s < p.splits; ++s) v += p.partial[(long)s * n + i];   // fixed order: deterministic
     if (p.bias) v += p.bias[col];
-    if (p.act == MVAE_ACT_SELU) v = selu_f(v);
+    if (p.act == MVAE_ACT_SELU) v = selu_f(v); else if (p.act == MVAE_ACT_RELU) v = fmaxf(v, 0.f);
     store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
   }
 }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs p) {
           p.partial[((long)split * p.M + row) * p.N + col] = v;
         } else {
           if (p.bias) v += p.bias[col];
-          if (p.act == MVAE_ACT_SELU) v = selu_f(v);
+          if (p.act == MVAE_ACT_SELU) v = selu_f(v); else if (p.act == MVAE_ACT_RELU) v = fmaxf(v, 0.f);
           store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
         }
       }

@@ -68,8 +68,10 @@ struct StepTaskF {
   void* c_save;                       // [B,H] dtype: cell state saved for backward
   void* h_out; long ldh;
   void* g_out;                        // [B,4H] dtype: post-activation gates saved for backward
+  const void* hprev_t0;               // GRU, t == 0 only: initial hidden state [B, ld = lda1] dtype (nullptr = zeros)
+  int t;                              // time index of this cell (GRU length masking)
 };
-struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_j, dbg, vec; };
+struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_j, dbg, vec, cell; };
 
 template <typename T, int BM, int BJ, int NBUF>   // NBUF == 0: generic register-staged main loop (any shape)
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
@@ -188,22 +190,40 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
     }
     float cp[8];
     if (q.c_prev) ldn<float>(q.c_prev + (long)row * H + j8, cp, n, vec);
+    else if (q.hprev_t0) ldn<T>(reinterpret_cast<const T*>(q.hprev_t0) + (long)row * q.lda1 + j8, cp, n, vec);
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) cp[e] = 0.f;
     }
-    float gi[8], gf[8], gg[8], go[8], c[8], h[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gi[e] = act_sigmoid<T>(pre[0][e]); gf[e] = act_sigmoid<T>(pre[1][e]); gg[e] = act_tanh<T>(pre[2][e]); go[e] = act_sigmoid<T>(pre[3][e]);
-      c[e] = gf[e] * cp[e] + gi[e] * gg[e];
-      h[e] = go[e] * act_tanh<T>(c[e]);
-    }
-    stn<float>(q.c_out + (long)row * H + j8, c, n, vec);
-    stn<T>(csave + (long)row * H + j8, c, n, vec);
-    stn<T>(hout + (long)row * q.ldh + j8, h, n, vec);
     T* g4 = gout + (long)row * 4 * H + j8;
-    stn<T>(g4, gi, n, vec); stn<T>(g4 + H, gf, n, vec); stn<T>(g4 + 2 * H, gg, n, vec); stn<T>(g4 + 3 * H, go, n, vec);
+    if (p.cell == MVAE_CELL_LSTM) {
+      float gi[8], gf[8], gg[8], go[8], c[8], h[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        gi[e] = act_sigmoid<T>(pre[0][e]); gf[e] = act_sigmoid<T>(pre[1][e]); gg[e] = act_tanh<T>(pre[2][e]); go[e] = act_sigmoid<T>(pre[3][e]);
+        c[e] = gf[e] * cp[e] + gi[e] * gg[e];
+        h[e] = go[e] * act_tanh<T>(c[e]);
+      }
+      stn<float>(q.c_out + (long)row * H + j8, c, n, vec);
+      stn<T>(csave + (long)row * H + j8, c, n, vec);
+      stn<T>(hout + (long)row * q.ldh + j8, h, n, vec);
+      stn<T>(g4, gi, n, vec); stn<T>(g4 + H, gf, n, vec); stn<T>(g4 + 2 * H, gg, n, vec); stn<T>(g4 + 3 * H, go, n, vec);
+    } else {
+      // GRU (torch.nn.GRU): slots = [r | z | W_in x + b_in | W_hn h + b_hn];  cp = h_{t-1} (fp32 recurrent state)
+      const bool valid = p.lengths ? (q.t < p.lengths[row]) : true;
+      float gr[8], gz[8], gn[8], hs_[8], hseq[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        gr[e] = act_sigmoid<T>(pre[0][e]); gz[e] = act_sigmoid<T>(pre[1][e]);
+        gn[e] = act_tanh<T>(pre[2][e] + gr[e] * pre[3][e]);
+        const float hn = (1.f - gz[e]) * gn[e] + gz[e] * cp[e];
+        hs_[e] = valid ? hn : cp[e];          // a finished sequence keeps its last state (pack_sequence semantics) ...
+        hseq[e] = valid ? hn : 0.f;           // ... and emits zeros (pad_packed_sequence)
+      }
+      stn<float>(q.c_out + (long)row * H + j8, hs_, n, vec);
+      stn<T>(hout + (long)row * q.ldh + j8, hseq, n, vec);
+      stn<T>(g4, gr, n, vec); stn<T>(g4 + H, gz, n, vec); stn<T>(g4 + 2 * H, gn, n, vec); stn<T>(g4 + 3 * H, pre[3], n, vec);
+    }
   }
 }
 
@@ -216,8 +236,11 @@ struct StepTaskB {
   const void* gates; const void* c; const void* c_prev;     // dtype
   const float* dc_in; float* dc_out;                        // fp32 ping-pong
   void* dG; long ldg;
+  const void* h_prev; long ldhp;      // GRU: h_{t-1} [B, ldhp] dtype (nullptr = zeros)
+  float* dh0;                         // GRU pseudo-cell t = -1: gradient w.r.t. the initial hidden state (fp32 [B,H]); gates == nullptr
+  int t;
 };
-struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; int ntask, B, H, tiles_m, tiles_n, dbg, vec; };
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell; };
 
 template <typename T, int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
@@ -312,42 +335,87 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
       const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
       dh[0] = a.x; dh[1] = a.y; dh[2] = a.z; dh[3] = a.w; dh[4] = b.x; dh[5] = b.y; dh[6] = b.z; dh[7] = b.w;
     }
-    if (q.dy) {
-      float a[8];
-      ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dh[e] += a[e];
-    }
-    float gi[8], gf[8], gg[8], go[8], c[8], cp[8], dci[8];
-    const T* g4 = gates + (long)row * 4 * H + j8;
-    ldn<T>(g4, gi, n, vec); ldn<T>(g4 + H, gf, n, vec); ldn<T>(g4 + 2 * H, gg, n, vec); ldn<T>(g4 + 3 * H, go, n, vec);
     const long o = (long)row * H + j8;
-    ldn<T>(cs + o, c, n, vec);
-    if (csp) ldn<T>(csp + o, cp, n, vec);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cp[e] = 0.f;
-    }
+    float dci[8];
     if (q.dc_in) ldn<float>(q.dc_in + o, dci, n, vec);
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) dci[e] = 0.f;
     }
-    float di[8], df[8], dg[8], dO[8], dco[8];
+    if (p.cell == MVAE_CELL_LSTM) {
+      if (q.dy) {
+        float a[8];
+        ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float tc = act_tanh<T>(c[e]);
-      const float d_o = dh[e] * tc;
-      const float dc = dh[e] * go[e] * (1.f - tc * tc) + dci[e];
-      dco[e] = dc * gf[e];
-      di[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
-      df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
-      dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
-      dO[e] = d_o * go[e] * (1.f - go[e]);
+        for (int e = 0; e < 8; ++e) dh[e] += a[e];
+      }
+      float gi[8], gf[8], gg[8], go[8], c[8], cp[8];
+      const T* g4 = gates + (long)row * 4 * H + j8;
+      ldn<T>(g4, gi, n, vec); ldn<T>(g4 + H, gf, n, vec); ldn<T>(g4 + 2 * H, gg, n, vec); ldn<T>(g4 + 3 * H, go, n, vec);
+      ldn<T>(cs + o, c, n, vec);
+      if (csp) ldn<T>(csp + o, cp, n, vec);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+      }
+      float di[8], df[8], dg[8], dO[8], dco[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float tc = act_tanh<T>(c[e]);
+        const float d_o = dh[e] * tc;
+        const float dc = dh[e] * go[e] * (1.f - tc * tc) + dci[e];
+        dco[e] = dc * gf[e];
+        di[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
+        df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+        dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
+        dO[e] = d_o * go[e] * (1.f - go[e]);
+      }
+      stn<float>(q.dc_out + o, dco, n, vec);
+      T* d4 = dG + (long)row * q.ldg + j8;
+      stn<T>(d4, di, n, vec); stn<T>(d4 + H, df, n, vec); stn<T>(d4 + 2 * H, dg, n, vec); stn<T>(d4 + 3 * H, dO, n, vec);
+    } else {
+      // GRU.  dh so far = dG^l_{t+1}[r,z,.,n*r] . W_hh + dG^{l+1}_t[r,z,n,.] . W_ih ; dci = the element-wise carry dh_{t+1} * z_{t+1}
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dh[e] += dci[e];
+      if (q.gates == nullptr) {                       // pseudo-cell t = -1: gradient w.r.t. the initial hidden state
+        stn<float>(q.dh0 + o, dh, n, vec);
+        continue;
+      }
+      const bool valid = p.lengths ? (q.t < p.lengths[row]) : true;
+      float dpr[8], dpz[8], dpn[8], dpnr[8], carry[8];
+      if (valid) {
+        if (q.dy) {
+          float a[8];
+          ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dh[e] += a[e];
+        }
+        float gr[8], gz[8], gn[8], nh[8], hp[8];
+        const T* g4 = gates + (long)row * 4 * H + j8;
+        ldn<T>(g4, gr, n, vec); ldn<T>(g4 + H, gz, n, vec); ldn<T>(g4 + 2 * H, gn, n, vec); ldn<T>(g4 + 3 * H, nh, n, vec);
+        if (q.h_prev) ldn<T>(reinterpret_cast<const T*>(q.h_prev) + (long)row * q.ldhp + j8, hp, n, vec);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hp[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dn = dh[e] * (1.f - gz[e]);
+          const float dz = dh[e] * (hp[e] - gn[e]);
+          dpn[e] = dn * (1.f - gn[e] * gn[e]);
+          dpr[e] = dpn[e] * nh[e] * gr[e] * (1.f - gr[e]);
+          dpz[e] = dz * gz[e] * (1.f - gz[e]);
+          dpnr[e] = dpn[e] * gr[e];
+          carry[e] = dh[e] * gz[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dpr[e] = 0.f; dpz[e] = 0.f; dpn[e] = 0.f; dpnr[e] = 0.f; carry[e] = dh[e]; }
+      }
+      stn<float>(q.dc_out + o, carry, n, vec);
+      T* d4 = dG + (long)row * q.ldg + j8;
+      stn<T>(d4, dpr, n, vec); stn<T>(d4 + H, dpz, n, vec); stn<T>(d4 + 2 * H, dpn, n, vec); stn<T>(d4 + 3 * H, dpnr, n, vec);
     }
-    stn<float>(q.dc_out + o, dco, n, vec);
-    T* d4 = dG + (long)row * q.ldg + j8;
-    stn<T>(d4, di, n, vec); stn<T>(d4 + H, df, n, vec); stn<T>(d4 + 2 * H, dg, n, vec); stn<T>(d4 + 3 * H, dO, n, vec);
   }
 }
 
@@ -373,13 +441,15 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (!d) return MVAE_ERR_INVALID;
-  if (d->cell != MVAE_CELL_LSTM) return MVAE_ERR_UNSUPPORTED;
+  if (d->cell != MVAE_CELL_LSTM && d->cell != MVAE_CELL_GRU) return MVAE_ERR_UNSUPPORTED;
   if (d->layers < 1 || d->layers > MVAE_MAX_LAYERS || d->T < 1 || d->B < 1 || d->H < 1) return MVAE_ERR_INVALID;
   if (d->dtype != MVAE_F32 && d->dtype != MVAE_BF16) return MVAE_ERR_INVALID;
   const int NL = d->layers, T = d->T, B = d->B, H = d->H, dt = d->dtype;
   const int epc = (dt == MVAE_BF16) ? 8 : 4;
+  const bool gru = d->cell == MVAE_CELL_GRU;
+  if (d->lengths && !gru) return MVAE_ERR_UNSUPPORTED;
   for (int l = 0; l < NL; ++l) {
-    if (!d->w_hh[l] || !d->hs[l] || !d->cs[l] || !d->gates[l] || !d->cstate[l]) return MVAE_ERR_INVALID;
+    if (!d->w_hh[l] || !d->hs[l] || (!gru && !d->cs[l]) || !d->gates[l] || !d->cstate[l]) return MVAE_ERR_INVALID;
     if (l > 0 && !d->w_ih[l]) return MVAE_ERR_INVALID;
     if (d->ldw_hh[l] % epc) return MVAE_ERR_INVALID;
     if (l > 0 && d->ldw_ih[l] % epc) return MVAE_ERR_INVALID;
@@ -411,9 +481,11 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   for (int l = 0; l < NL; ++l) {
     if ((4L * H) * d->ldw_hh[l] * sz >= (1L << 31) || d->ldw_hh[l] % (16 / sz)) pipe = false;
     if ((l > 0 || d->x0) && ((4L * H) * d->ldw_ih[l] * sz >= (1L << 31) || d->ldw_ih[l] % (16 / sz))) pipe = false;
-    if (!al16(d->hs[l]) || !al16(d->cs[l]) || !al16(d->gates[l]) || !al16(d->cstate[l]) || (d->bias[l] && !al16(d->bias[l]))) vec = false;
+    if (!al16(d->hs[l]) || (!gru && !al16(d->cs[l])) || !al16(d->gates[l]) || !al16(d->cstate[l]) || (d->bias[l] && !al16(d->bias[l]))) vec = false;
+    if (d->h0[l] && (!al16(d->h0[l]) || d->ldh0 % 8)) vec = false;
   }
   StepArgsF a;
+  a.lengths = d->lengths; a.cell = d->cell;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + 31) / 32; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
   const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
@@ -442,7 +514,9 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       q.bias = d->bias[l];
       q.c_prev = (t > 0) ? d->cstate[l] + (long)((t - 1) & 1) * B * H : nullptr;
       q.c_out = d->cstate[l] + (long)(t & 1) * B * H;
-      q.c_save = const_cast<char*>(adv(d->cs[l], (long)t * B * H, dt));
+      q.c_save = gru ? nullptr : const_cast<char*>(adv(d->cs[l], (long)t * B * H, dt));
+      q.hprev_t0 = (gru && t == 0) ? d->h0[l] : nullptr;
+      q.t = t;
       q.h_out = const_cast<char*>(adv(d->hs[l], (long)t * B * d->ldh, dt)); q.ldh = d->ldh;
       q.g_out = const_cast<char*>(adv(d->gates[l], (long)t * B * 4 * H, dt));
     }
@@ -464,14 +538,17 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
 
 int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   if (!d) return MVAE_ERR_INVALID;
-  if (d->cell != MVAE_CELL_LSTM) return MVAE_ERR_UNSUPPORTED;
+  if (d->cell != MVAE_CELL_LSTM && d->cell != MVAE_CELL_GRU) return MVAE_ERR_UNSUPPORTED;
   if (d->layers < 1 || d->layers > MVAE_MAX_LAYERS || d->T < 1 || d->B < 1 || d->H < 1) return MVAE_ERR_INVALID;
   if (d->dtype != MVAE_F32 && d->dtype != MVAE_BF16) return MVAE_ERR_INVALID;
   const int NL = d->layers, T = d->T, B = d->B, H = d->H, dt = d->dtype;
   const int epc = (dt == MVAE_BF16) ? 8 : 4;
-  if (!d->dy) return MVAE_ERR_INVALID;
+  const bool gru = d->cell == MVAE_CELL_GRU;
+  if (!d->dy && !gru) return MVAE_ERR_INVALID;
+  if (d->lengths && !gru) return MVAE_ERR_UNSUPPORTED;
   for (int l = 0; l < NL; ++l) {
-    if (!d->w_hhT[l] || !d->cs[l] || !d->gates[l] || !d->dG[l] || !d->dstate[l]) return MVAE_ERR_INVALID;
+    if (!d->w_hhT[l] || (!gru && !d->cs[l]) || !d->gates[l] || !d->dG[l] || !d->dstate[l]) return MVAE_ERR_INVALID;
+    if (gru && !d->hs[l]) return MVAE_ERR_INVALID;
     if (l > 0 && !d->w_ihT[l]) return MVAE_ERR_INVALID;
     if (d->ldw_hhT[l] % epc || (l > 0 && d->ldw_ihT[l] % epc)) return MVAE_ERR_INVALID;
   }
@@ -486,22 +563,41 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   if (BM != 32) BN = 64;
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
   bool pipe = ((4 * H) % ke == 0) && ((long)B * ldg * sz < (1L << 31)) && (ldg % (16 / sz) == 0);
-  bool vec = (H % 8 == 0) && (ldg % 8 == 0) && al16(d->dy) && (d->dy_ld % 4 == 0);
+  bool vec = (H % 8 == 0) && (ldg % 8 == 0) && (!d->dy || (al16(d->dy) && (d->dy_ld % 4 == 0)));
   for (int l = 0; l < NL; ++l) {
     if ((long)H * d->ldw_hhT[l] * sz >= (1L << 31) || d->ldw_hhT[l] % (16 / sz)) pipe = false;
     if (l > 0 && ((long)H * d->ldw_ihT[l] * sz >= (1L << 31) || d->ldw_ihT[l] % (16 / sz))) pipe = false;
-    if (!al16(d->cs[l]) || !al16(d->gates[l]) || !al16(d->dG[l]) || !al16(d->dstate[l])) vec = false;
+    if ((!gru && !al16(d->cs[l])) || !al16(d->gates[l]) || !al16(d->dG[l]) || !al16(d->dstate[l])) vec = false;
+    if (gru && (!al16(d->hs[l]) || d->ldh % 8 || (d->h0[l] && (!al16(d->h0[l]) || d->ldh0 % 8)))) vec = false;
+    if (d->dh_last[l] && !al16(d->dh_last[l])) vec = false;
+    if (d->dh0[l] && !al16(d->dh0[l])) vec = false;
   }
   StepArgsB a;
+  a.lengths = d->lengths; a.cell = d->cell;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
   const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
   size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + BN) * KB;
   const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
-  for (int e = T + NL - 2; e >= 0; --e) {
+  bool want_dh0 = false;
+  for (int l = 0; l < NL; ++l) want_dh0 = want_dh0 || (gru && d->dh0[l]);
+  for (int e = T + NL - 2; e >= (want_dh0 ? -1 : 0); --e) {
     int n = 0;
-    for (int l = 0; l < NL; ++l) {
+    if (e < 0) {
+      // GRU pseudo-cells t = -1: dh0[l] = dG^l_0[r,z,.,n*r] . W_hh^l + (element-wise carry of t = 0)
+      for (int l = 0; l < NL; ++l) {
+        if (!d->dh0[l]) continue;
+        StepTaskB& q = a.t[n++];
+        q.A0 = d->dG[l]; q.lda0 = ldg; q.K0 = 4 * H; q.W0 = d->w_hhT[l]; q.ldw0 = d->ldw_hhT[l];
+        q.A1 = nullptr; q.lda1 = ldg; q.K1 = 4 * H; q.W1 = nullptr; q.ldw1 = 0;
+        q.dy = nullptr; q.dy_ld = 0; q.gates = nullptr; q.c = nullptr; q.c_prev = nullptr;
+        q.dc_in = d->dstate[l]; q.dc_out = nullptr; q.dG = nullptr; q.ldg = ldg; q.h_prev = nullptr; q.ldhp = 0;
+        q.dh0 = d->dh0[l]; q.t = -1;
+      }
+      if (n == 0) break;
+    }
+    for (int l = 0; l < NL && e >= 0; ++l) {
       const int t = e - l;
       if (t < 0 || t >= T) continue;
       StepTaskB& q = a.t[n++];
@@ -509,11 +605,14 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       q.lda0 = ldg; q.K0 = 4 * H; q.W0 = d->w_hhT[l]; q.ldw0 = d->ldw_hhT[l];
       q.A1 = (l < NL - 1) ? adv(d->dG[l + 1], (long)t * B * ldg, dt) : nullptr;
       q.lda1 = ldg; q.K1 = 4 * H; q.W1 = (l < NL - 1) ? d->w_ihT[l + 1] : nullptr; q.ldw1 = (l < NL - 1) ? d->ldw_ihT[l + 1] : 0;
-      q.dy = (l == NL - 1) ? d->dy + (long)t * B * d->dy_ld : nullptr; q.dy_ld = d->dy_ld;
+      q.dy = (l == NL - 1 && d->dy) ? d->dy + (long)t * B * d->dy_ld : nullptr; q.dy_ld = d->dy_ld;
       q.gates = adv(d->gates[l], (long)t * B * 4 * H, dt);
-      q.c = adv(d->cs[l], (long)t * B * H, dt);
-      q.c_prev = (t > 0) ? adv(d->cs[l], (long)(t - 1) * B * H, dt) : nullptr;
-      q.dc_in = (t < T - 1) ? d->dstate[l] + (long)((t + 1) & 1) * B * H : nullptr;
+      q.c = gru ? nullptr : adv(d->cs[l], (long)t * B * H, dt);
+      q.c_prev = (!gru && t > 0) ? adv(d->cs[l], (long)(t - 1) * B * H, dt) : nullptr;
+      q.dc_in = (t < T - 1) ? d->dstate[l] + (long)((t + 1) & 1) * B * H : (gru ? d->dh_last[l] : nullptr);
+      q.h_prev = gru ? ((t > 0) ? adv(d->hs[l], (long)(t - 1) * B * d->ldh, dt) : d->h0[l]) : nullptr;
+      q.ldhp = (t > 0) ? d->ldh : d->ldh0;
+      q.dh0 = nullptr; q.t = t;
       q.dc_out = d->dstate[l] + (long)(t & 1) * B * H;
       q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * ldg, dt)); q.ldg = ldg;
     }
@@ -532,3 +631,4 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
+

@@ -1,0 +1,350 @@
+"""Host-side mirror of ``mosesvae.VAE`` (mosesvae.py:27-199): GRU encoder / 3-layer GRU decoder character VAE.
+
+Same constructor (``VAE(vocab)``), hard-coded hyper-parameters (mosesvae.py:31-40), attribute names, aliasing ``ModuleList``s
+(88 ``state_dict`` keys over 29 tensors) and ``forward`` 6-tuple ``(kl_loss, recon_loss, z, logvar, x, y)`` as the reference.
+The whole forward is one ``torch.autograd.Function`` over the C ABI: embedding folded into the layer-0 GRU input projection
+(a table gather), wavefront GRU kernels with per-sequence length masking (== pack_sequence / pad_packed_sequence semantics:
+a finished sequence keeps its state and emits zeros), fused heads + reparameterisation + KL, fused token cross-entropy.
+
+Not reproduced this round: the decoder's inter-layer dropout (``d_dropout = 0.2``, train mode only, mosesvae.py:73-79) -- the
+kernels compute the deterministic (eval-mode) network; ``VAE.d_dropout`` is kept for introspection.  ``sample()`` (inference,
+broken upstream: SURVEY section 0) is out of scope.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD
+
+
+class ReLU(nn.Module):
+    """Marker (fused into the producing GEMM's epilogue)."""
+
+
+def _slots4(w3, H, order):
+    """[3H, K] gate rows (r, z, n) -> [4H, K] slot rows; order 'x' = (r, z, n, 0) for W_ih, 'h' = (r, z, 0, n) for W_hh."""
+    out = torch.zeros(4 * H, *w3.shape[1:], dtype=w3.dtype, device=w3.device)
+    out[:2 * H] = w3[:2 * H]
+    if order == "x":
+        out[2 * H:3 * H] = w3[2 * H:]
+    else:
+        out[3 * H:] = w3[2 * H:]
+    return out
+
+
+class VAE(nn.Module):
+    def __init__(self, vocab, dtype=torch.bfloat16):
+        super().__init__()
+        q_d_h, q_n_layers, d_n_layers, d_dropout, d_z, d_d_h = 256, 1, 3, 0.2, 160, 512     # mosesvae.py:31-40
+        self.vocabulary = vocab
+        for ss in ("bos", "eos", "unk", "pad"):
+            setattr(self, ss, getattr(vocab, ss))
+        n_vocab, d_emb = len(vocab), vocab.vectors.size(1)
+        self.x_emb = EmbeddingWeights(n_vocab, d_emb)
+        self.x_emb.padding_idx = self.pad
+        self.x_emb.weight.data.copy_(vocab.vectors)                 # mosesvae.py:50 (overwrites the zeroed pad row too)
+        self.encoder_rnn = RNNWeights("GRU", d_emb, q_d_h, q_n_layers)
+        self.q_mu = nn.Sequential(LinearWeights(q_d_h, 256), ReLU(), LinearWeights(256, d_z))
+        self.q_logvar = nn.Sequential(LinearWeights(q_d_h, 256), ReLU(), LinearWeights(256, d_z))
+        self.decoder_rnn = RNNWeights("GRU", d_emb + d_z, d_d_h, d_n_layers)
+        self.decoder_lat = LinearWeights(d_z, d_d_h)
+        self.decoder_fc = LinearWeights(d_d_h, n_vocab)
+        self.encoder = nn.ModuleList([self.x_emb, self.encoder_rnn, self.q_mu, self.q_logvar])
+        self.decoder = nn.ModuleList([self.decoder_rnn, self.decoder_lat, self.decoder_fc])
+        self.vae = nn.ModuleList([self.x_emb, self.encoder, self.decoder])
+        self.d_z, self.d_dropout = d_z, d_dropout
+        self.compute_dtype = dtype
+        self._ws = _Workspace()
+        self._pack_key, self._packed = None, {}
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def string2tensor(self, string, device="model"):
+        ids = self.vocabulary.string2ids(string, add_bos=True, add_eos=True)
+        return torch.tensor(ids, dtype=torch.long, device=self.device if device == "model" else device)
+
+    def tensor2string(self, tensor):
+        return self.vocabulary.ids2string(tensor.tolist(), rem_bos=True, rem_eos=True)
+
+    # -- unique parameters in a fixed order (parameters() already de-duplicates the aliases)
+    def _plist(self):
+        return list(self.parameters())
+
+    def forward(self, x, eps=None):
+        """x: list of LongTensors (one per sequence, sorted by length descending, as collate() yields them).
+        Returns (kl_loss, recon_loss, z, logvar, x_padded, y) -- mosesvae.py:126-140."""
+        dev = self.device
+        lengths = [int(t.numel()) for t in x]
+        if any(lengths[i] < lengths[i + 1] for i in range(len(lengths) - 1)):
+            raise RuntimeError("sequences must be sorted by length in decreasing order (pack_sequence, mosesvae.py:151)")
+        B, T = len(x), max(lengths)
+        # one packed host->device transfer instead of one .cuda() per sequence (moses_train_distrib.py:271)
+        x_pad = torch.full((B, T), self.pad, dtype=torch.long)
+        for b, t in enumerate(x):
+            x_pad[b, :lengths[b]] = t.cpu() if t.device.type != "cpu" else t
+        x_pad = x_pad.to(dev, non_blocking=True)
+        len_t = torch.tensor(lengths, dtype=torch.int32).to(dev, non_blocking=True)
+        if eps is None:
+            eps = torch.randn(B, self.d_z, device=dev)              # mosesvae.py:159 randn_like(mu): device generator
+        kl, recon, z, logvar, y = _MosesFn.apply(self, x_pad, len_t, eps.contiguous().float(), *self._plist())
+        return kl, recon, z, logvar, x_pad, y
+
+    def forward_encoder(self, x, eps=None):
+        kl, _, z, logvar, _, _ = self.forward(x, eps)
+        return z, kl, logvar
+
+    # -- packed shadows
+    def _pack(self, dev):
+        params = self._plist()
+        key = _params_key(params) + (self.compute_dtype,)
+        if key == self._pack_key:
+            return self._packed
+        ws, dt, f32 = self._ws, self.compute_dtype, torch.float32
+        V = self.x_emb.num_embeddings
+        Vp = _pad(V, 4)
+        P = {}
+        with torch.no_grad():
+            E = self.x_emb.weight
+            P["E_p"] = ws.get("E_p", (V, Vp), f32, dev); ops.cast_transpose(E, V, V, dst=P["E_p"])
+            P["ET_p"] = ws.get("ET_p", (V, Vp), f32, dev); ops.cast_transpose(E, V, V, dstT=P["ET_p"])
+            for name, rnn, nl in (("enc", self.encoder_rnn, 1), ("dec", self.decoder_rnn, self.decoder_rnn.num_layers)):
+                H = rnn.hidden_size
+                ldw, ldwT = H + _LDPAD, 4 * H + _LDPAD
+                P[name] = dict(H=H, ldw=ldw, ldwT=ldwT, Whh=[], WhhT=[], Wih=[None], WihT=[None], bias=[])
+                for l in range(nl):
+                    whh4 = _slots4(getattr(rnn, f"weight_hh_l{l}"), H, "h")
+                    w = ws.get(f"{name}_Whh{l}", (4 * H, ldw), dt, dev); wT = ws.get(f"{name}_WhhT{l}", (H, ldwT), dt, dev)
+                    ops.cast_transpose(whh4, 4 * H, H, dst=w, dstT=wT)
+                    P[name]["Whh"].append(w); P[name]["WhhT"].append(wT)
+                    if l > 0:
+                        wih4 = _slots4(getattr(rnn, f"weight_ih_l{l}"), H, "x")
+                        w = ws.get(f"{name}_Wih{l}", (4 * H, ldw), dt, dev); wT = ws.get(f"{name}_WihT{l}", (H, ldwT), dt, dev)
+                        ops.cast_transpose(wih4, 4 * H, H, dst=w, dstT=wT)
+                        P[name]["Wih"].append(w); P[name]["WihT"].append(wT)
+                    bi, bh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
+                    b4 = ws.get(f"{name}_bias{l}", (4 * H,), f32, dev)
+                    b4[:2 * H] = bi[:2 * H] + bh[:2 * H]; b4[2 * H:3 * H] = bi[2 * H:]; b4[3 * H:] = bh[2 * H:]
+                    P[name]["bias"].append(b4)
+                # layer-0 input weights: the embedding part becomes a table, the z part (decoder) a dense projection
+                w0 = getattr(rnn, "weight_ih_l0")
+                wx = ws.get(f"{name}_Wx_p", (3 * H, Vp), f32, dev); ops.cast_transpose(w0[:, :V].contiguous(), 3 * H, V, dst=wx)
+                wxT = ws.get(f"{name}_WxT", (V, 3 * H), f32, dev); ops.cast_transpose(w0[:, :V].contiguous(), 3 * H, V, dstT=wxT)
+                P[name]["Wx_p"], P[name]["WxT"] = wx, wxT
+            dz = self.d_z
+            Hd = P["dec"]["H"]
+            w0 = self.decoder_rnn.weight_ih_l0
+            P["Wz"] = ws.get("dec_Wz", (3 * Hd, dz), f32, dev); P["Wz"].copy_(w0[:, V:])
+            P["WzT"] = ws.get("dec_WzT", (dz, 3 * Hd), f32, dev); ops.cast_transpose(P["Wz"], 3 * Hd, dz, dstT=P["WzT"])
+            for n, seq in (("mu", self.q_mu), ("lv", self.q_logvar)):
+                P[n + "_W0T"] = ws.get(n + "_W0T", (seq[0].in_features, seq[0].out_features), f32, dev)
+                ops.cast_transpose(seq[0].weight, seq[0].out_features, seq[0].in_features, dstT=P[n + "_W0T"])
+                P[n + "_W2T"] = ws.get(n + "_W2T", (seq[2].in_features, seq[2].out_features), f32, dev)
+                ops.cast_transpose(seq[2].weight, seq[2].out_features, seq[2].in_features, dstT=P[n + "_W2T"])
+            P["WlatT"] = ws.get("WlatT", (dz, Hd), f32, dev); ops.cast_transpose(self.decoder_lat.weight, Hd, dz, dstT=P["WlatT"])
+            Vp8 = _pad(V, 8)
+            P["Wfc"] = ws.get("Wfc", (V, Hd + _LDPAD), dt, dev); P["WfcT"] = ws.get("WfcT", (Hd, Vp8), dt, dev)
+            ops.cast_transpose(self.decoder_fc.weight, V, Hd, dst=P["Wfc"], dstT=P["WfcT"])
+        self._pack_key, self._packed = key, P
+        return P
+
+
+def _kmajor_gemm(ws, tag, A, lda, M, Bm, ldb, N, K, out, dev):
+    """out[M,N] = A[:K,:M]^T . Bm[:K,:N] for K-major operands: TN kernel for bf16, transposes + NT for f32."""
+    if A.dtype == torch.bfloat16:
+        ops.gemm_tn(A, Bm, out, M, N, K, lda=lda, ldb=ldb)
+        return
+    ldT = _pad(K, 8) + 8
+    AT = ws.get(tag + "_AT", (M, ldT), torch.float32, dev); BT = ws.get(tag + "_BT", (N, ldT), torch.float32, dev)
+    ops.cast_transpose(A, K, M, dstT=AT, lds=lda); ops.cast_transpose(Bm, K, N, dstT=BT, lds=ldb)
+    ops.gemm_nt(AT, BT, out, M, N, ldT, lda=ldT, ldb=ldT)
+
+
+class _MosesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x_pad, lengths, eps, *params):
+        dev = x_pad.device
+        _require_cuda(dev, "mosesvae.VAE")
+        P = mod._pack(dev)
+        ws, dt, f32 = mod._ws, mod.compute_dtype, torch.float32
+        ws.generation += 1
+        B, T = x_pad.shape
+        V, dz = mod.x_emb.num_embeddings, mod.d_z
+        Vp = _pad(V, 4)
+        W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
+        # ---------------- encoder GRU (mosesvae.py:150-156): embedding folded into a [V, 4H] table
+        pe = P["enc"]; Hq = pe["H"]
+        tbl3 = W("enc_tbl3", (V, 3 * Hq)); ops.gemm_nt(P["E_p"], pe["Wx_p"], tbl3, V, 3 * Hq, Vp)
+        tbl4 = W("enc_tbl4", (V, 4 * Hq)); tbl4[:, :3 * Hq].copy_(tbl3)
+        add_e = W("enc_add", (T, B, 4 * Hq)); ops.gather_rows_tb(x_pad, tbl4, add_e, B, T, V, 4 * Hq)
+        ldh_e = Hq + _LDPAD
+        hsx_e = [W("enc_hsx0", (T + 1, B, ldh_e), dt)]                 # slot 0 = initial state (zeros), slots 1.. = outputs
+        gates_e = [W("enc_gates0", (T, B, 4 * Hq), dt)]
+        hstate_e = [W("enc_hstate0", (2, B, Hq))]
+        ops.rnn_fwd(L.CELL_GRU, dt, T, B, Hq, add_e, B * 4 * Hq, pe["Wih"], [pe["ldw"]], pe["Whh"], [pe["ldw"]], pe["bias"],
+                    [hsx_e[0][1:]], ldh_e, None, gates_e, hstate_e, lengths=lengths)
+        h_last = hstate_e[0][(T - 1) & 1]                               # fp32 [B,Hq]: last valid state of every sequence
+        # ---------------- heads + reparameterisation + KL (mosesvae.py:158-162)
+        m1 = W("m1", (B, 256)); l1 = W("l1", (B, 256)); mu = W("mu", (B, dz)); lv = W("lv", (B, dz))
+        ops.gemm_nt(h_last, mod.q_mu[0].weight, m1, B, 256, Hq, bias=mod.q_mu[0].bias, act=L.ACT_RELU)
+        ops.gemm_nt(m1, mod.q_mu[2].weight, mu, B, dz, 256, bias=mod.q_mu[2].bias)
+        ops.gemm_nt(h_last, mod.q_logvar[0].weight, l1, B, 256, Hq, bias=mod.q_logvar[0].bias, act=L.ACT_RELU)
+        ops.gemm_nt(l1, mod.q_logvar[2].weight, lv, B, dz, 256, bias=mod.q_logvar[2].bias)
+        z = torch.empty(B, dz, device=dev); kl = torch.empty(1, device=dev)
+        ops.moses_latent_fwd(mu, lv, eps, z, kl, B, dz)
+        # ---------------- decoder (mosesvae.py:172-197)
+        pd = P["dec"]; Hd = pd["H"]; NL = mod.decoder_rnn.num_layers
+        h0 = W("h0", (B, Hd)); ops.gemm_nt(z, mod.decoder_lat.weight, h0, B, Hd, dz, bias=mod.decoder_lat.bias)
+        tbl3d = W("dec_tbl3", (V, 3 * Hd)); ops.gemm_nt(P["E_p"], pd["Wx_p"], tbl3d, V, 3 * Hd, Vp)
+        tbl4d = W("dec_tbl4", (V, 4 * Hd)); tbl4d[:, :3 * Hd].copy_(tbl3d)
+        zp3 = W("zp3", (B, 3 * Hd)); ops.gemm_nt(z, P["Wz"], zp3, B, 3 * Hd, dz)
+        zp4 = W("zp4", (B, 4 * Hd)); zp4[:, :3 * Hd].copy_(zp3)
+        add_d = W("dec_add", (T, B, 4 * Hd)); ops.gather_rows_tb(x_pad, tbl4d, add_d, B, T, V, 4 * Hd, base=zp4)
+        ldh_d = Hd + _LDPAD
+        hsx_d = [W(f"dec_hsx{l}", (T + 1, B, ldh_d), dt) for l in range(NL)]
+        for l in range(NL):
+            ops.cast_transpose(h0, B, Hd, dst=hsx_d[l][0])              # h_0 = decoder_lat(z) for every layer (mosesvae.py:185-186)
+        gates_d = [W(f"dec_gates{l}", (T, B, 4 * Hd), dt) for l in range(NL)]
+        hstate_d = [W(f"dec_hstate{l}", (2, B, Hd)) for l in range(NL)]
+        ops.rnn_fwd(L.CELL_GRU, dt, T, B, Hd, add_d, B * 4 * Hd, pd["Wih"], [pd["ldw"]] * NL, pd["Whh"], [pd["ldw"]] * NL, pd["bias"],
+                    [h[1:] for h in hsx_d], ldh_d, None, gates_d, hstate_d, h0=[h[0] for h in hsx_d], ldh0=ldh_d, lengths=lengths)
+        TB = T * B
+        y_tb = W("y_tb", (TB, V))
+        ops.gemm_nt(hsx_d[-1][1:].reshape(TB, ldh_d), P["Wfc"], y_tb, TB, V, Hd, bias=mod.decoder_fc.bias)
+        y = torch.empty(B, T, V, device=dev); ops.permute102(y_tb, y, T, B, V)
+        loss2 = W("loss2", (2,)); ops.ce_loss_fwd(y_tb, V, x_pad, mod.pad, loss2, B, T, V)
+        ctx.mod, ctx.gen, ctx.x_pad, ctx.lengths, ctx.eps = mod, ws.generation, x_pad, lengths, eps
+        ctx.set_materialize_grads(False)
+        return kl[0].clone(), loss2[0].clone(), z, lv.clone(), y
+
+    @staticmethod
+    def backward(ctx, dkl, drecon, dz_ext, dlv_ext, dy_ext):
+        mod, x_pad, lengths, eps = ctx.mod, ctx.x_pad, ctx.lengths, ctx.eps
+        ws = mod._ws
+        if ws.generation != ctx.gen:
+            raise L.MvaeError("mosesvae.VAE workspace was overwritten by a later forward; run backward before the next forward")
+        dev = x_pad.device
+        P, dt, f32 = mod._packed, mod.compute_dtype, torch.float32
+        B, T = x_pad.shape
+        V, dz = mod.x_emb.num_embeddings, mod.d_z
+        Vp, Vp8, TB, Bp = _pad(V, 4), _pad(V, 8), T * B, _pad(B, 4)
+        W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
+        params = mod._plist()
+        names = [n for n, _ in mod.named_parameters()]
+        gflat = torch.zeros(sum(p.numel() for p in params), dtype=f32, device=dev)
+        grads, off = {}, 0
+        for n, p in zip(names, params):
+            grads[n] = gflat[off:off + p.numel()].view(p.shape); off += p.numel()
+        c = lambda t: t.contiguous().float() if t is not None else None
+        g1 = lambda t: c(t).reshape(1) if t is not None else None
+        pe, pd = P["enc"], P["dec"]
+        Hq, Hd, NL = pe["H"], pd["H"], mod.decoder_rnn.num_layers
+        ldh_e, ldh_d = Hq + _LDPAD, Hd + _LDPAD
+
+        def lin_bwd(tag, dy, x, WT, wname, bname, M_in, N_out, need_dx=True):
+            """y = x W^T + b:  dW = dy^T x, db = colsum(dy), dx = dy W (via the packed transpose WT [in, out])."""
+            dyT, xT = W(tag + "_dyT", (N_out, Bp)), W(tag + "_xT", (M_in, Bp))
+            ops.cast_transpose(dy, B, N_out, dstT=dyT); ops.cast_transpose(x, B, M_in, dstT=xT)
+            ops.gemm_nt(dyT, xT, grads[wname], N_out, M_in, Bp)
+            ops.colsum(dy, B, N_out, grads[bname])
+            if not need_dx:
+                return None
+            dx = W(tag + "_dx", (B, M_in))
+            ops.gemm_nt(dy, WT, dx, B, M_in, N_out)
+            return dx
+
+        # ---------------- decoder_fc + cross-entropy
+        y_tb, loss2 = W("y_tb", (TB, V)), W("loss2", (2,))
+        dl = W("dl", (TB + 8, Vp8), dt)[:TB]
+        if drecon is None:
+            drecon = torch.zeros((), device=dev)
+        ops.ce_loss_bwd(y_tb, V, x_pad, mod.pad, loss2, g1(drecon), c(dy_ext), dl, B, T, V)
+        hsx_d = [W(f"dec_hsx{l}", (T + 1, B, ldh_d), dt) for l in range(NL)]
+        out_seq = hsx_d[-1][1:].reshape(TB, ldh_d)
+        _kmajor_gemm(ws, "fc", dl, Vp8, V, out_seq, ldh_d, Hd, TB, grads["decoder_fc.weight"], dev)
+        dbp = W("dbfc_p", (Vp8,)); ops.colsum_t(dl, TB, Vp8, dbp, ldx=Vp8); grads["decoder_fc.bias"].copy_(dbp[:V])
+        dyd = W("dy_dec", (TB, Hd)); ops.gemm_nt(dl, P["WfcT"], dyd, TB, Hd, Vp8)
+        # ---------------- decoder GRU stack, reverse wavefront (+ gradient w.r.t. h_0 of every layer)
+        ldg_d = 4 * Hd + _LDPAD
+        gates_d = [W(f"dec_gates{l}", (T, B, 4 * Hd), dt) for l in range(NL)]
+        dG_d = [W(f"dec_dG{l}", (T, B, ldg_d), dt) for l in range(NL)]
+        dstate_d = [W(f"dec_dstate{l}", (2, B, Hd)) for l in range(NL)]
+        dh0 = [W(f"dec_dh0_{l}", (B, Hd)) for l in range(NL)]
+        ops.rnn_bwd(L.CELL_GRU, dt, T, B, Hd, pd["WhhT"], [pd["ldwT"]] * NL, pd["WihT"], [pd["ldwT"]] * NL, dyd, Hd,
+                    [h[1:] for h in hsx_d], ldh_d, None, gates_d, dG_d, dstate_d, ldg=ldg_d, h0=[h[0] for h in hsx_d], ldh0=ldh_d,
+                    lengths=lengths, dh0=dh0)
+        s4 = W("dec_s4", (4 * Hd,))
+        for l in range(NL):
+            a = dG_d[l].view(TB, ldg_d)
+            hprev = hsx_d[l][:T].reshape(TB, ldh_d)                  # h_{t-1} for every t (slot 0 = h_0)
+            gw = grads[f"decoder_rnn.weight_hh_l{l}"]
+            _kmajor_gemm(ws, "dwhh_rz", a, ldg_d, 2 * Hd, hprev, ldh_d, Hd, TB, gw[:2 * Hd], dev)
+            _kmajor_gemm(ws, "dwhh_n", a[:, 3 * Hd:], ldg_d, Hd, hprev, ldh_d, Hd, TB, gw[2 * Hd:], dev)
+            if l > 0:
+                _kmajor_gemm(ws, "dwih", a, ldg_d, 3 * Hd, hsx_d[l - 1][1:].reshape(TB, ldh_d), ldh_d, Hd, TB,
+                             grads[f"decoder_rnn.weight_ih_l{l}"], dev)
+            ops.colsum_t(a, TB, 4 * Hd, s4, ldx=ldg_d)
+            grads[f"decoder_rnn.bias_ih_l{l}"].copy_(s4[:3 * Hd])
+            grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
+        # layer-0 input = [emb(x_t), z]: table scatter for the embedding part, time sum for the z part
+        dtbl4 = W("dec_dtbl4", (V, 4 * Hd)); ops.scatter_rows_tb(x_pad, dG_d[0], dtbl4, B, T, V, 4 * Hd, ldd=ldg_d)
+        dtbl3 = W("dec_dtbl3", (V, 3 * Hd)); dtbl3.copy_(dtbl4[:, :3 * Hd])
+        dE = W("dE", (V, V)); ops.gemm_nt(dtbl3, pd["WxT"], dE, V, V, 3 * Hd)
+        dtblT = W("dec_dtblT", (3 * Hd, Vp)); ops.cast_transpose(dtbl3, V, 3 * Hd, dstT=dtblT)
+        dwx = W("dec_dwx", (3 * Hd, V)); ops.gemm_nt(dtblT, P["ET_p"], dwx, 3 * Hd, V, Vp)
+        dzp4 = W("dzp4", (B, ldg_d)); ops.timesum(dG_d[0], T, B, ldg_d, dzp4)
+        dzp3 = W("dzp3", (B, 3 * Hd)); dzp3.copy_(dzp4[:, :3 * Hd])
+        z = W("z_saved", (B, dz))      # filled below from mu/lv/eps (z is recomputed: it was an output tensor)
+        mu, lv = W("mu", (B, dz)), W("lv", (B, dz))
+        torch.addcmul(mu, torch.exp(lv * 0.5), eps, out=z)           # plumbing-sized [B,160] recompute of z
+        dzp3T, zT = W("dzp3T", (3 * Hd, Bp)), W("zT", (dz, Bp))
+        ops.cast_transpose(dzp3, B, 3 * Hd, dstT=dzp3T); ops.cast_transpose(z, B, dz, dstT=zT)
+        dwz = W("dec_dwz", (3 * Hd, dz)); ops.gemm_nt(dzp3T, zT, dwz, 3 * Hd, dz, Bp)
+        gw0 = grads["decoder_rnn.weight_ih_l0"]; gw0[:, :V].copy_(dwx); gw0[:, V:].copy_(dwz)
+        dz_tot = W("dz_tot", (B, dz)); ops.gemm_nt(dzp3, P["WzT"], dz_tot, B, dz, 3 * Hd)
+        # h_0 = decoder_lat(z), shared by the layers
+        dh0s = dh0[0]
+        for l in range(1, NL):
+            dh0s.add_(dh0[l])
+        dzl = lin_bwd("lat", dh0s, z, P["WlatT"], "decoder_lat.weight", "decoder_lat.bias", dz, Hd)
+        dz_tot.add_(dzl)
+        if dz_ext is not None:
+            dz_tot.add_(c(dz_ext))
+        # ---------------- reparameterisation + KL, heads
+        dmu, dlv = W("dmu", (B, dz)), W("dlv", (B, dz))
+        ops.moses_latent_bwd(mu, lv, eps, dz_tot, g1(dkl), c(dlv_ext), dmu, dlv, B, dz)
+        m1, l1 = W("m1", (B, 256)), W("l1", (B, 256))
+        h_last = W("enc_hstate0", (2, B, Hq))[(T - 1) & 1]
+        dm1 = lin_bwd("mu2", dmu, m1, P["mu_W2T"], "q_mu.2.weight", "q_mu.2.bias", 256, dz); ops.relu_bwd(dm1, m1)
+        dhq = lin_bwd("mu0", dm1, h_last, P["mu_W0T"], "q_mu.0.weight", "q_mu.0.bias", Hq, 256)
+        dhq_tot = W("dhq_tot", (B, Hq)); dhq_tot.copy_(dhq)
+        dl1 = lin_bwd("lv2", dlv, l1, P["lv_W2T"], "q_logvar.2.weight", "q_logvar.2.bias", 256, dz); ops.relu_bwd(dl1, l1)
+        dhq2 = lin_bwd("lv0", dl1, h_last, P["lv_W0T"], "q_logvar.0.weight", "q_logvar.0.bias", Hq, 256)
+        dhq_tot.add_(dhq2)
+        # ---------------- encoder GRU: only the final state receives gradient; masked steps pass it back to each sequence's last step
+        ldg_e = 4 * Hq + _LDPAD
+        hsx_e = [W("enc_hsx0", (T + 1, B, ldh_e), dt)]
+        gates_e = [W("enc_gates0", (T, B, 4 * Hq), dt)]
+        dG_e = [W("enc_dG0", (T, B, ldg_e), dt)]
+        dstate_e = [W("enc_dstate0", (2, B, Hq))]
+        ops.rnn_bwd(L.CELL_GRU, dt, T, B, Hq, pe["WhhT"], [pe["ldwT"]], pe["WihT"], [pe["ldwT"]], None, 0,
+                    [hsx_e[0][1:]], ldh_e, None, gates_e, dG_e, dstate_e, ldg=ldg_e, h0=[hsx_e[0][0]], ldh0=ldh_e,
+                    lengths=lengths, dh_last=[dhq_tot])
+        a = dG_e[0].view(TB, ldg_e)
+        hprev = hsx_e[0][:T].reshape(TB, ldh_e)
+        gw = grads["encoder_rnn.weight_hh_l0"]
+        _kmajor_gemm(ws, "e_dwhh_rz", a, ldg_e, 2 * Hq, hprev, ldh_e, Hq, TB, gw[:2 * Hq], dev)
+        _kmajor_gemm(ws, "e_dwhh_n", a[:, 3 * Hq:], ldg_e, Hq, hprev, ldh_e, Hq, TB, gw[2 * Hq:], dev)
+        s4e = W("enc_s4", (4 * Hq,)); ops.colsum_t(a, TB, 4 * Hq, s4e, ldx=ldg_e)
+        grads["encoder_rnn.bias_ih_l0"].copy_(s4e[:3 * Hq])
+        grads["encoder_rnn.bias_hh_l0"][:2 * Hq].copy_(s4e[:2 * Hq]); grads["encoder_rnn.bias_hh_l0"][2 * Hq:].copy_(s4e[3 * Hq:])
+        etbl4 = W("enc_dtbl4", (V, 4 * Hq)); ops.scatter_rows_tb(x_pad, dG_e[0], etbl4, B, T, V, 4 * Hq, ldd=ldg_e)
+        etbl3 = W("enc_dtbl3", (V, 3 * Hq)); etbl3.copy_(etbl4[:, :3 * Hq])
+        dE2 = W("dE2", (V, V)); ops.gemm_nt(etbl3, pe["WxT"], dE2, V, V, 3 * Hq)
+        etblT = W("enc_dtblT", (3 * Hq, Vp)); ops.cast_transpose(etbl3, V, 3 * Hq, dstT=etblT)
+        ops.gemm_nt(etblT, P["ET_p"], grads["encoder_rnn.weight_ih_l0"], 3 * Hq, V, Vp)
+        ge = grads["x_emb.weight"]; torch.add(dE, dE2, out=ge)
+        ge[mod.pad].zero_()                                           # nn.Embedding(padding_idx=pad): no gradient to the pad row
+        return (None, None, None, None) + tuple(grads[n] for n in names)

@@ -112,8 +112,37 @@ def permute021(inp, out, N, A, Bd):
     check(L.load().mvae_permute021(N, A, Bd, ptr(inp), ptr(out), stream_ptr()), "mvae_permute021")
 
 
-def gather_rows_tb(idx, table, out, B, Lq, nrows, W):
-    check(L.load().mvae_gather_rows_tb(ptr(idx), B, Lq, nrows, ptr(table), W, ptr(out), stream_ptr()), "mvae_gather_rows_tb")
+def gather_rows_tb(idx, table, out, B, Lq, nrows, W, base=None):
+    check(L.load().mvae_gather_rows_tb(ptr(idx), B, Lq, nrows, ptr(table), W, ptr(base), ptr(out), stream_ptr()), "mvae_gather_rows_tb")
+
+
+def relu_bwd(dy, y):
+    check(L.load().mvae_relu_bwd(dy.numel(), ptr(dy), ptr(y), stream_ptr()), "mvae_relu_bwd")
+
+
+def permute102(inp, out, T, B, V):
+    check(L.load().mvae_permute102(T, B, V, ptr(inp), ptr(out), stream_ptr()), "mvae_permute102")
+
+
+def moses_latent_fwd(mu, logvar, eps, z, kl, B, dz):
+    check(L.load().mvae_moses_latent_fwd(B, dz, ptr(mu), ptr(logvar), ptr(eps), ptr(z), ptr(kl), stream_ptr()), "mvae_moses_latent_fwd")
+
+
+def moses_latent_bwd(mu, logvar, eps, dz_in, dkl, dlogvar_ext, dmu, dlogvar, B, dz):
+    check(L.load().mvae_moses_latent_bwd(B, dz, ptr(mu), ptr(logvar), ptr(eps), ptr(dz_in), ptr(dkl), ptr(dlogvar_ext), ptr(dmu), ptr(dlogvar),
+                                         stream_ptr()), "mvae_moses_latent_bwd")
+
+
+def ce_loss_fwd(logits, ldl, x, pad, loss2, B, T, V):
+    lib = L.load()
+    need = lib.mvae_ce_loss_workspace(B, T)
+    ws = Scratch.get(need, logits.device)
+    check(lib.mvae_ce_loss_fwd(B, T, V, ptr(logits), ldl, ptr(x), pad, ptr(loss2), ptr(ws), need, stream_ptr()), "mvae_ce_loss_fwd")
+
+
+def ce_loss_bwd(logits, ldl, x, pad, loss2, grad_out, dy_ext, dl, B, T, V):
+    check(L.load().mvae_ce_loss_bwd(dt_code(dl.dtype), B, T, V, ptr(logits), ldl, ptr(x), pad, ptr(loss2), ptr(grad_out), ptr(dy_ext), ptr(dl),
+                                    dl.stride(0), stream_ptr()), "mvae_ce_loss_bwd")
 
 
 def scatter_rows_tb(idx, d, dtable, B, Lq, nrows, W, ldd=None):
