@@ -229,6 +229,13 @@ int mvae_bce_kl_loss_bwd(int64_t n_recon, const float* recon, const float* targe
                          float* dlogvar, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Device-side input pipeline: the encoded data set lives in HBM as uint8 indices [N, L]; a batch is the
+ * rows `rows[0..B)` expanded to what MoleLoader.__getitem__ + default collate produce (data_loader.py:26-31): int64 indices
+ * [B, L] and, when ohe != NULL, the float one-hot [B, L, C].
+ */
+int mvae_expand_indices(const uint8_t* store, const int64_t* rows, int B, int L, int C, int64_t* idx, float* ohe, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * MOSES GRU path (mosesvae.py:126-199).
  *   mvae_moses_latent_*: z = mu + exp(logvar/2)*eps and kl = 0.5*mean_b sum_j(exp(logvar) + mu^2 - 1 - logvar)  (mosesvae.py:158-162);
  *     backward adds dkl * d(kl) and an optional external dlogvar (logvar is a return value of VAE.forward).

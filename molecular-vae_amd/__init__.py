@@ -7,10 +7,11 @@ from . import _lib  # noqa: F401
 from .models import (MolecularVAE, MolEncoder, MolDecoder, Lambda, ConvSELU, SELU, TimeDistributed, Repeat,  # noqa: F401
                      Flatten)
 from .functional import bce_kl_loss, make_loss_function  # noqa: F401
-from . import mosesvae, vocab  # noqa: F401
+from . import mosesvae, vocab, data  # noqa: F401
+from .data import MoleLoader, DeviceDataset, build_vocab, encode_smiles  # noqa: F401
 from .vocab import CharVocab, OneHotVocab  # noqa: F401
 from .train import FusedAdam, GradSync, ShardedSampler, shard_batch, train_step, exact_match_accuracy  # noqa: F401
 
-__all__ = ["mosesvae", "vocab", "CharVocab", "OneHotVocab", "MolecularVAE", "MolEncoder", "MolDecoder", "Lambda", "ConvSELU", "SELU", "TimeDistributed", "Repeat",
+__all__ = ["mosesvae", "vocab", "data", "MoleLoader", "DeviceDataset", "build_vocab", "encode_smiles", "CharVocab", "OneHotVocab", "MolecularVAE", "MolEncoder", "MolDecoder", "Lambda", "ConvSELU", "SELU", "TimeDistributed", "Repeat",
            "Flatten", "bce_kl_loss", "make_loss_function", "FusedAdam", "GradSync", "ShardedSampler", "shard_batch",
            "train_step", "exact_match_accuracy"]

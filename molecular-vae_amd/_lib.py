@@ -84,6 +84,7 @@ SIGNATURES = {
     "mvae_bce_kl_loss_workspace": (_sz, [_i64, _i64]),
     "mvae_bce_kl_loss_fwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "mvae_bce_kl_loss_bwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_expand_indices": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mvae_moses_latent_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvae_moses_latent_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvae_ce_loss_workspace": (_sz, [_i, _i]),

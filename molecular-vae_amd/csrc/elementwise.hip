@@ -407,6 +407,22 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, float* p, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------- device-side input pipeline
+// rows[b] selects a molecule of the uint8 index store [N, L] resident in HBM; emits what MoleLoader.__getitem__ + the default collate
+// yield (data_loader.py:26-31): int64 indices [B, L] and the float one-hot [B, L, C].
+__global__ __launch_bounds__(256) void expand_indices_kernel(const uint8_t* store, const int64_t* rows, int B, int L, int C, int64_t* idx, float* ohe) {
+  const long n = (long)B * L;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / L), t = (int)(i - (long)b * L);
+    const int v = store[rows[b] * L + t];
+    idx[i] = v;
+    if (ohe) {
+      float* o = ohe + i * C;
+      for (int c = 0; c < C; ++c) o[c] = (c == v) ? 1.f : 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- MOSES path (mosesvae.py)
 __global__ __launch_bounds__(256) void relu_bwd_kernel(long n, float* dy, const float* y) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dy[i] = y[i] > 0.f ? dy[i] : 0.f;
@@ -592,6 +608,12 @@ size_t mvae_colsum_workspace(int M, int N) { return colsum_workspace_bytes(M, N)
 int mvae_colsum(int M, int N, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream) {
   if (!X || !out || M < 0) return MVAE_ERR_INVALID;
   return launch_colsum(M, N, X, ldx, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int mvae_expand_indices(const uint8_t* store, const int64_t* rows, int B, int L, int C, int64_t* idx, float* ohe, void* stream) {
+  if (!store || !rows || !idx || B < 1 || L < 1 || C < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(expand_indices_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, (hipStream_t)stream, store, rows, B, L, C, idx, ohe);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
 }
 int mvae_relu_bwd(int64_t n, float* dy, const float* y, void* stream) {
   if (!dy || !y) return MVAE_ERR_INVALID;

@@ -116,6 +116,10 @@ def gather_rows_tb(idx, table, out, B, Lq, nrows, W, base=None):
     check(L.load().mvae_gather_rows_tb(ptr(idx), B, Lq, nrows, ptr(table), W, ptr(base), ptr(out), stream_ptr()), "mvae_gather_rows_tb")
 
 
+def expand_indices(store, rows, idx, ohe, B, Lq, C_):
+    check(L.load().mvae_expand_indices(ptr(store), ptr(rows), B, Lq, C_, ptr(idx), ptr(ohe), stream_ptr()), "mvae_expand_indices")
+
+
 def relu_bwd(dy, y):
     check(L.load().mvae_relu_bwd(dy.numel(), ptr(dy), ptr(y), stream_ptr()), "mvae_relu_bwd")
 
