@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const uint32_t bytesA = (uint32_t)((long)p.M * p.lda * sz - kbeg * sz), bytesB = (uint32_t)((long)p.N * p.ldb * sz - kbeg * sz);
     pipe_seg_init<T, BM, BN>(s0, A + kbeg, bytesA, B + kbeg, bytesB, offA, offB, (int)(kend - kbeg), tid);
     s1 = s0; s1.nk = 0;
-    tile_gemm_pipe<T, BM, BN, MI, NI, NBUF, 16>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    tile_gemm_pipe<T, BM, BN, MI, NI, NBUF, NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
   } else {
     tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, kbeg, kend, wm * WM, brow, acc, tid);
   }

@@ -77,8 +77,9 @@ template <typename T, int BM, int BJ, int NBUF>   // NBUF == 0: generic register
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   constexpr bool PIPE = NBUF > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(BJ == 32, "one 16-wide hidden sub-tile per wave and gate");
-  constexpr int BN = 4 * BJ, WM = BM / 2, MI = WM / 16, NI = 4;
+  static_assert(BJ == 32 || BJ == 64, "hidden units per tile");
+  constexpr int JS = BJ / 32;                  // 16-wide hidden sub-tiles per wave and gate
+  constexpr int BN = 4 * BJ, WM = BM / 2, MI = WM / 16, NI = 4 * JS;     // acc[mi][g * JS + s]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wj = wave & 1;
   const int per_task = p.tiles_m * p.tiles_j;
   const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task);
@@ -109,11 +110,11 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
       auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)(4 * H) * ldw, offA, offB, q.K1, tid);
     }
-    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), BJ>(smem, s0, s1, wm * WM, wj * 16, acc, tid);
+    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), JS, BJ>(smem, s0, s1, wm * WM, wj * (BJ / 2), acc, tid);
   } else {
     int brow[NI];
 #pragma unroll
-    for (int g = 0; g < NI; ++g) brow[g] = g * BJ + wj * 16;
+    for (int g = 0; g < NI; ++g) brow[g] = (g / JS) * BJ + wj * (BJ / 2) + (g % JS) * 16;
     if (q.A0 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A0);
       const T* W = reinterpret_cast<const T*>(q.W0);
@@ -141,15 +142,16 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int g = 0; g < NI; ++g)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wm * WM + i * 16 + lq * 4 + r;
-          stg[(row * 4 + g) * SJ + wj * 16 + lr] = acc[i][g][r];
+          stg[(row * 4 + ni / JS) * SJ + wj * (BJ / 2) + (ni % JS) * 16 + lr] = acc[i][ni][r];
         }
   }
   __syncthreads();
-  const int g8 = tid & 3;                      // constant per thread: 8-unit group inside the BJ = 32 tile
+  constexpr int GPRW = BJ / 8;                 // 8-unit groups per tile row
+  const int g8 = tid % GPRW;                   // constant per thread
   const int j8 = j0 + g8 * 8;
   if (j8 >= H) return;
   const int n = (H - j8 < 8) ? (H - j8) : 8;
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   T* gout = reinterpret_cast<T*>(q.g_out);
   T* csave = reinterpret_cast<T*>(q.c_save);
 #pragma unroll
-  for (int it = 0; it < (BM * 4 + 255) / 256; ++it) {
-    const int lrow = (tid >> 2) + it * 64;
+  for (int it = 0; it < (BM * GPRW + 255) / 256; ++it) {
+    const int lrow = tid / GPRW + it * (256 / GPRW);
     const int row = m0 + lrow;
     if (lrow >= BM || row >= B) continue;
     float pre[4][8];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, q.K1, tid);
     }
-    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), 16>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
   } else {
     int brow[NI];
 #pragma unroll
@@ -486,11 +488,17 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   }
   StepArgsF a;
   a.lengths = d->lengths; a.cell = d->cell;
-  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + 31) / 32; a.vec = vec ? 1 : 0;
+  // wide tile (128 rows x 64 units x 4 gates, one workgroup per CU): (128 + 256) operand rows per 32768 outputs -- half the L2->LDS
+  // traffic per output of the 64 x 128 tile; used when it still gives >= 256 workgroups per full launch.  MVAE_BJ overrides.
+  int BJ = (pipe && dt == MVAE_BF16 && (long)((B + 127) / 128) * ((H + 63) / 64) * NL >= 256) ? 64 : 32;
+  BJ = tune_int("MVAE_BJ", BJ);
+  if (BJ == 64 && (!pipe || dt != MVAE_BF16)) BJ = 32;
+  if (BJ == 64) BM = 128;
+  a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + BJ - 1) / BJ; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
-  const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
-  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 128) * KB;
-  const size_t stage_bytes = (size_t)BM * 4 * (32 + 4) * sizeof(float);     // epilogue staging tile
+  const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (BJ == 64) ? 3 : (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
+  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 4 * BJ) * KB;
+  const size_t stage_bytes = (size_t)BM * 4 * (BJ + 4) * sizeof(float);     // epilogue staging tile
   if (lds < stage_bytes) lds = stage_bytes;
   for (int dd = 0; dd < T + NL - 1; ++dd) {
     int n = 0;
@@ -522,7 +530,8 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_j), block(256);
-#define FWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
+#define FWD_CASE(TT_, BM_, NB_) if (BJ == 32 && BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
+    if (BJ == 64 && nbuf == 3) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3>)); continue; }
     if (dt == MVAE_BF16) {
       FWD_CASE(bf16_t, 128, 0) FWD_CASE(bf16_t, 128, 3) FWD_CASE(bf16_t, 128, 4) FWD_CASE(bf16_t, 128, 5)
       FWD_CASE(bf16_t, 64, 0) FWD_CASE(bf16_t, 64, 3) FWD_CASE(bf16_t, 64, 4) FWD_CASE(bf16_t, 64, 5)

@@ -68,23 +68,34 @@ template <int I, int N, int STRIDE> struct FragRead {
 template <int N, int STRIDE> struct FragRead<N, N, STRIDE> {
   static __device__ __forceinline__ void run(u32x4 (&)[N], uint32_t) {}
 };
+// B fragments whose n-sub-tiles form groups: sub-tile I lives at LDS row (I / JS) * BOUT + (I % JS) * 16 of the wave's B region
+// (plain GEMM: JS = N, one group of consecutive 16-row sub-tiles; LSTM forward: one group per gate, BOUT = rows per gate).
+template <int I, int N, int JS, int BOUT> struct FragReadB {
+  static __device__ __forceinline__ void run(u32x4 (&dst)[N], uint32_t addr) {
+    dst[I] = lds_read128<((I / JS) * BOUT + (I % JS) * 16) * KB>(addr);
+    FragReadB<I + 1, N, JS, BOUT>::run(dst, addr);
+  }
+};
+template <int N, int JS, int BOUT> struct FragReadB<N, N, JS, BOUT> {
+  static __device__ __forceinline__ void run(u32x4 (&)[N], uint32_t) {}
+};
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
   __builtin_amdgcn_sched_barrier(0);     // nothing (in particular no earlier MFMA) may sink below / later MFMA rise above the wait
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// MFMAs of one K-step from LDS byte addresses (stage base already added).  BSTRIDE = LDS rows between
-// consecutive n-sub-tiles of this wave.  a_lane / b_lane: per-lane byte offsets of (row l&15, chunk kk*4 + l>>4)
+// MFMAs of one K-step from LDS byte addresses (stage base already added).  JS / BOUT: layout of the wave's n-sub-tiles
+// (FragReadB).  a_lane / b_lane: per-lane byte offsets of (row l&15, chunk kk*4 + l>>4)
 // for kk = 0,1 relative to the wave's first A / B row.
-template <typename T, int MI, int NI, int BSTRIDE>
+template <typename T, int MI, int NI, int JS, int BOUT>
 __device__ __forceinline__ void tile_mma_asm(uint32_t a_base, uint32_t b_base, const uint32_t (&a_lane)[2], const uint32_t (&b_lane)[2],
                                              f32x4 (&acc)[MI][NI]) {
   u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
   FragRead<0, MI, 16 * KB>::run(a0, a_base + a_lane[0]);
-  FragRead<0, NI, BSTRIDE * KB>::run(b0, b_base + b_lane[0]);
+  FragReadB<0, NI, JS, BOUT>::run(b0, b_base + b_lane[0]);
   FragRead<0, MI, 16 * KB>::run(a1, a_base + a_lane[1]);
-  FragRead<0, NI, BSTRIDE * KB>::run(b1, b_base + b_lane[1]);
+  FragReadB<0, NI, JS, BOUT>::run(b1, b_base + b_lane[1]);
   wait_lgkmcnt<(MI + NI) < 16 ? (MI + NI) : 15>();
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -121,12 +132,13 @@ __device__ __forceinline__ void pipe_issue_stage(char* smem, const PipeSeg<BM, B
 }
 
 // acc += sum over segment 0 then segment 1 of A_tile . B_tile^T.   smem: NBUF * (BM + BN) * 128 bytes.
-template <typename T, int BM, int BN, int MI, int NI, int NBUF, int BSTRIDE>
+template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT>
 __device__ __forceinline__ void tile_gemm_pipe(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int arow0,
                                                int brow0, f32x4 (&acc)[MI][NI], int tid) {
   constexpr int STAGE = (BM + BN) * KB;
   constexpr int LPS = (BM + BN) * 8 / 256;          // buffer loads per thread per stage
   static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
+  static_assert((BM + BN) * 8 % 256 == 0 && BM * 8 % 256 == 0, "whole LDS-DMA pieces per thread");
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = s0.nk + s1.nk;
@@ -149,7 +161,7 @@ __device__ __forceinline__ void tile_gemm_pipe(char* smem, const PipeSeg<BM, BN>
     asm volatile("" ::: "memory");                            // keep the fragment reads below the barrier
     if (kt + NBUF - 1 < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, wave);   // refill the buffer stage kt-1 used
     const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
-    tile_mma_asm<T, MI, NI, BSTRIDE>(st, st, a_lane, b_lane, acc);
+    tile_mma_asm<T, MI, NI, JS, BOUT>(st, st, a_lane, b_lane, acc);
   }
   __builtin_amdgcn_s_barrier();                               // LDS free for the caller (epilogue scratch / next use)
 }

@@ -139,6 +139,17 @@ def test_lstm_wavefront_fwd_bwd_vs_oracle(case):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("env", [{"MVAE_BJ": "64"}, {"MVAE_BM": "128", "MVAE_NBUF_FWD": "4", "MVAE_NBUF_BWD": "5"},
+                                 {"MVAE_BM": "64", "MVAE_BJ": "32", "MVAE_NBUF_FWD": "5", "MVAE_NBUF_BWD": "3"}])
+def test_lstm_tile_variants_vs_oracle(env, monkeypatch):
+    """The tile / ring-depth variants the heuristics pick at production sizes, forced here at an oracle-checkable size."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    errs = _lstm_case(torch.bfloat16, 4, 200, 192, 3, 8)
+    bad = {k: v for k, v in errs.items() if v > 3e-2}
+    assert not bad, bad
+
+
 def test_small_ops_vs_oracle():
     rs = np.random.RandomState(3)
     B, Lq, C, o = 5, 11, 12, 16
