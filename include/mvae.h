@@ -157,6 +157,8 @@ typedef struct {
   void* dGh[MVAE_MAX_LAYERS];                                              /* GRU only: W_hh-side gradient rows */
   float* dstate[MVAE_MAX_LAYERS];                                         /* fp32 [2][B][H] ping-pong: LSTM dc, GRU dh carry */
   float* dh0[MVAE_MAX_LAYERS];                                            /* optional out: gradient w.r.t. h0 (GRU decoder_lat path) */
+  void* split_ws; size_t split_ws_bytes;                                  /* optional scratch >= layers*2*B*H*4 bytes: enables the split-segment
+                                                                             schedule (128x128 partial tiles + element-wise second launch) */
 } mvae_rnn_bwd_desc;
 
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream);

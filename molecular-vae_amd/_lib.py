@@ -47,7 +47,8 @@ class RnnBwdDesc(C.Structure):
                 ("dG", _vp * MAX_LAYERS), ("ldg", _i64),
                 ("dGh", _vp * MAX_LAYERS),
                 ("dstate", _vp * MAX_LAYERS),
-                ("dh0", _vp * MAX_LAYERS)]
+                ("dh0", _vp * MAX_LAYERS),
+                ("split_ws", _vp), ("split_ws_bytes", _sz)]
 
 
 # name -> (restype, argtypes); mirrors include/mvae.h one to one (tests check every symbol is exported)

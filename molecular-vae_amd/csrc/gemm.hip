@@ -4,6 +4,7 @@
 // output alone cannot fill 256 CUs.  Blocks are remapped so that consecutive tiles of one XCD share A rows.
 #include "tile_pipe.hpp"
 #include "kernels.hpp"
+#include <stdlib.h>
 
 struct GemmArgs {
   const void* A; const void* B; void* C; const float* bias; float* partial;
@@ -284,10 +285,16 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
     p.partial = reinterpret_cast<float*>(ws);
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(256);
-  auto kern = gemm_tn_bf16_kernel<4>;
+  // ring depth 4 (128 KiB); MVAE_NBUF_TN=3 (96 KiB, leaves room for a second workgroup of another stream on the CU) was measured: slower
+  static int nbuf_tn = getenv("MVAE_NBUF_TN") ? atoi(getenv("MVAE_NBUF_TN")) : 4;
   static bool attr_set = false;
-  if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-  hipLaunchKernelGGL(kern, grid, block, 4 * 32768, st, p);
+  if (!attr_set) {
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (nbuf_tn == 4) hipLaunchKernelGGL(gemm_tn_bf16_kernel<4>, grid, block, 4 * 32768, st, p);
+  else hipLaunchKernelGGL(gemm_tn_bf16_kernel<3>, grid, block, 3 * 32768, st, p);
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;

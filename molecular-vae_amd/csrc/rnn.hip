@@ -73,7 +73,8 @@ struct StepTaskF {
 };
 struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_j, dbg, vec, cell; };
 
-template <typename T, int BM, int BJ, int NBUF>   // NBUF == 0: generic register-staged main loop (any shape)
+// NBUF > 0: LDS-direct ring of that depth; NBUF == 0: generic register-staged loop (any shape)
+template <typename T, int BM, int BJ, int NBUF>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   constexpr bool PIPE = NBUF > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -242,7 +243,98 @@ struct StepTaskB {
   float* dh0;                         // GRU pseudo-cell t = -1: gradient w.r.t. the initial hidden state (fp32 [B,H]); gates == nullptr
   int t;
 };
-struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell; };
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split; };
+
+// Gate-derivative math of one (batch row, 8 hidden units) group, given dh = sum of the two contractions (fp32).
+template <typename T>
+__device__ __forceinline__ void bwd_cell_group(const StepArgsB& p, const StepTaskB& q, int row, int j8, int n, bool vec, float (&dh)[8]) {
+  const int H = p.H;
+  const T* gates = reinterpret_cast<const T*>(q.gates);
+  const T* cs = reinterpret_cast<const T*>(q.c);
+  const T* csp = reinterpret_cast<const T*>(q.c_prev);
+  T* dG = reinterpret_cast<T*>(q.dG);
+  const long o = (long)row * H + j8;
+  float dci[8];
+  if (q.dc_in) ldn<float>(q.dc_in + o, dci, n, vec);
+  else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dci[e] = 0.f;
+  }
+  if (p.cell == MVAE_CELL_LSTM) {
+    if (q.dy) {
+      float a[8];
+      ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dh[e] += a[e];
+    }
+    float gi[8], gf[8], gg[8], go[8], c[8], cp[8];
+    const T* g4 = gates + (long)row * 4 * H + j8;
+    ldn<T>(g4, gi, n, vec); ldn<T>(g4 + H, gf, n, vec); ldn<T>(g4 + 2 * H, gg, n, vec); ldn<T>(g4 + 3 * H, go, n, vec);
+    ldn<T>(cs + o, c, n, vec);
+    if (csp) ldn<T>(csp + o, cp, n, vec);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+    }
+    float di[8], df[8], dg[8], dO[8], dco[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float tc = act_tanh<T>(c[e]);
+      const float d_o = dh[e] * tc;
+      const float dc = dh[e] * go[e] * (1.f - tc * tc) + dci[e];
+      dco[e] = dc * gf[e];
+      di[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
+      df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+      dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
+      dO[e] = d_o * go[e] * (1.f - go[e]);
+    }
+    stn<float>(q.dc_out + o, dco, n, vec);
+    T* d4 = dG + (long)row * q.ldg + j8;
+    stn<T>(d4, di, n, vec); stn<T>(d4 + H, df, n, vec); stn<T>(d4 + 2 * H, dg, n, vec); stn<T>(d4 + 3 * H, dO, n, vec);
+  } else {
+    // GRU.  dh so far = dG^l_{t+1}[r,z,.,n*r] . W_hh + dG^{l+1}_t[r,z,n,.] . W_ih ; dci = the element-wise carry dh_{t+1} * z_{t+1}
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dh[e] += dci[e];
+    if (q.gates == nullptr) {                       // pseudo-cell t = -1: gradient w.r.t. the initial hidden state
+      stn<float>(q.dh0 + o, dh, n, vec);
+      return;
+    }
+    const bool valid = p.lengths ? (q.t < p.lengths[row]) : true;
+    float dpr[8], dpz[8], dpn[8], dpnr[8], carry[8];
+    if (valid) {
+      if (q.dy) {
+        float a[8];
+        ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dh[e] += a[e];
+      }
+      float gr[8], gz[8], gn[8], nh[8], hp[8];
+      const T* g4 = gates + (long)row * 4 * H + j8;
+      ldn<T>(g4, gr, n, vec); ldn<T>(g4 + H, gz, n, vec); ldn<T>(g4 + 2 * H, gn, n, vec); ldn<T>(g4 + 3 * H, nh, n, vec);
+      if (q.h_prev) ldn<T>(reinterpret_cast<const T*>(q.h_prev) + (long)row * q.ldhp + j8, hp, n, vec);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hp[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dn = dh[e] * (1.f - gz[e]);
+        const float dz = dh[e] * (hp[e] - gn[e]);
+        dpn[e] = dn * (1.f - gn[e] * gn[e]);
+        dpr[e] = dpn[e] * nh[e] * gr[e] * (1.f - gr[e]);
+        dpz[e] = dz * gz[e] * (1.f - gz[e]);
+        dpnr[e] = dpn[e] * gr[e];
+        carry[e] = dh[e] * gz[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dpr[e] = 0.f; dpz[e] = 0.f; dpn[e] = 0.f; dpnr[e] = 0.f; carry[e] = dh[e]; }
+    }
+    stn<float>(q.dc_out + o, carry, n, vec);
+    T* d4 = dG + (long)row * q.ldg + j8;
+    stn<T>(d4, dpr, n, vec); stn<T>(d4 + H, dpz, n, vec); stn<T>(d4 + 2 * H, dpn, n, vec); stn<T>(d4 + 3 * H, dpnr, n, vec);
+  }
+}
 
 template <typename T, int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
@@ -251,12 +343,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int per_task = p.tiles_m * p.tiles_n;
-  const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task);
-  const int task = bid / per_task;
-  const int rem = bid - task * per_task;
+  const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task * (p.split ? 2 : 1));
+  const int task2 = bid / per_task;
+  const int task = p.split ? (task2 >> 1) : task2;
+  const int seg = task2 & 1;                     // split mode: this workgroup contracts ONE of the two K-segments
+  const int rem = bid - task2 * per_task;
   const int tn = rem / p.tiles_m, tm = rem - tn * p.tiles_m;
   const StepTaskB& q = p.t[task];
   const int m0 = tm * BM, n0 = tn * BN, H = p.H, B = p.B;
+  if (p.split && (seg == 0 ? q.A0 == nullptr : q.A1 == nullptr)) return;   // this cell has no such segment: the epilogue kernel skips it too
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -272,12 +367,14 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)H * ldw, offA, offB, q.K0, tid);
+      if (p.split && seg == 1) s0.nk = 0;
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, q.K1, tid);
+      if (p.split && seg == 0) s1.nk = 0;
     }
     tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
   } else {
@@ -322,10 +419,21 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
   if (j8 >= H) return;
   const int n = (H - j8 < 8) ? (H - j8) : 8;
   const bool vec = p.vec != 0;
-  const T* gates = reinterpret_cast<const T*>(q.gates);
-  const T* cs = reinterpret_cast<const T*>(q.c);
-  const T* csp = reinterpret_cast<const T*>(q.c_prev);
-  T* dG = reinterpret_cast<T*>(q.dG);
+  if (p.split) {
+    // split mode (host guarantees whole tiles and the vector path): store this segment's fp32 partial tile; lstm_bwd_epi_kernel sums
+    float* part = p.partial + ((long)(task * 2 + seg) * B) * H;
+#pragma unroll
+    for (int it = 0; it < (BM * GPR + 255) / 256; ++it) {
+      const int lrow = tid / GPR + it * (256 / GPR);
+      const int row = m0 + lrow;
+      if (lrow >= BM || row >= B) continue;
+      const float* sp = stg + lrow * SN + g8 * 8;
+      float* dst = part + (long)row * H + j8;
+      *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(sp);
+      *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(sp + 4);
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < (BM * GPR + 255) / 256; ++it) {
     const int lrow = tid / GPR + it * (256 / GPR);
@@ -337,88 +445,31 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
       const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
       dh[0] = a.x; dh[1] = a.y; dh[2] = a.z; dh[3] = a.w; dh[4] = b.x; dh[5] = b.y; dh[6] = b.z; dh[7] = b.w;
     }
-    const long o = (long)row * H + j8;
-    float dci[8];
-    if (q.dc_in) ldn<float>(q.dc_in + o, dci, n, vec);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dci[e] = 0.f;
-    }
-    if (p.cell == MVAE_CELL_LSTM) {
-      if (q.dy) {
-        float a[8];
-        ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dh[e] += a[e];
-      }
-      float gi[8], gf[8], gg[8], go[8], c[8], cp[8];
-      const T* g4 = gates + (long)row * 4 * H + j8;
-      ldn<T>(g4, gi, n, vec); ldn<T>(g4 + H, gf, n, vec); ldn<T>(g4 + 2 * H, gg, n, vec); ldn<T>(g4 + 3 * H, go, n, vec);
-      ldn<T>(cs + o, c, n, vec);
-      if (csp) ldn<T>(csp + o, cp, n, vec);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cp[e] = 0.f;
-      }
-      float di[8], df[8], dg[8], dO[8], dco[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float tc = act_tanh<T>(c[e]);
-        const float d_o = dh[e] * tc;
-        const float dc = dh[e] * go[e] * (1.f - tc * tc) + dci[e];
-        dco[e] = dc * gf[e];
-        di[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
-        df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
-        dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
-        dO[e] = d_o * go[e] * (1.f - go[e]);
-      }
-      stn<float>(q.dc_out + o, dco, n, vec);
-      T* d4 = dG + (long)row * q.ldg + j8;
-      stn<T>(d4, di, n, vec); stn<T>(d4 + H, df, n, vec); stn<T>(d4 + 2 * H, dg, n, vec); stn<T>(d4 + 3 * H, dO, n, vec);
-    } else {
-      // GRU.  dh so far = dG^l_{t+1}[r,z,.,n*r] . W_hh + dG^{l+1}_t[r,z,n,.] . W_ih ; dci = the element-wise carry dh_{t+1} * z_{t+1}
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dh[e] += dci[e];
-      if (q.gates == nullptr) {                       // pseudo-cell t = -1: gradient w.r.t. the initial hidden state
-        stn<float>(q.dh0 + o, dh, n, vec);
-        continue;
-      }
-      const bool valid = p.lengths ? (q.t < p.lengths[row]) : true;
-      float dpr[8], dpz[8], dpn[8], dpnr[8], carry[8];
-      if (valid) {
-        if (q.dy) {
-          float a[8];
-          ldn<float>(q.dy + (long)row * q.dy_ld + j8, a, n, vec);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dh[e] += a[e];
-        }
-        float gr[8], gz[8], gn[8], nh[8], hp[8];
-        const T* g4 = gates + (long)row * 4 * H + j8;
-        ldn<T>(g4, gr, n, vec); ldn<T>(g4 + H, gz, n, vec); ldn<T>(g4 + 2 * H, gn, n, vec); ldn<T>(g4 + 3 * H, nh, n, vec);
-        if (q.h_prev) ldn<T>(reinterpret_cast<const T*>(q.h_prev) + (long)row * q.ldhp + j8, hp, n, vec);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) hp[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float dn = dh[e] * (1.f - gz[e]);
-          const float dz = dh[e] * (hp[e] - gn[e]);
-          dpn[e] = dn * (1.f - gn[e] * gn[e]);
-          dpr[e] = dpn[e] * nh[e] * gr[e] * (1.f - gr[e]);
-          dpz[e] = dz * gz[e] * (1.f - gz[e]);
-          dpnr[e] = dpn[e] * gr[e];
-          carry[e] = dh[e] * gz[e];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { dpr[e] = 0.f; dpz[e] = 0.f; dpn[e] = 0.f; dpnr[e] = 0.f; carry[e] = dh[e]; }
-      }
-      stn<float>(q.dc_out + o, carry, n, vec);
-      T* d4 = dG + (long)row * q.ldg + j8;
-      stn<T>(d4, dpr, n, vec); stn<T>(d4 + H, dpz, n, vec); stn<T>(d4 + 2 * H, dpn, n, vec); stn<T>(d4 + 3 * H, dpnr, n, vec);
-    }
+    bwd_cell_group<T>(p, q, row, j8, n, vec, dh);
   }
+}
+
+// Split mode, second launch: dh = partial(seg 0) + partial(seg 1), then the gate-derivative math.  One thread per (row, 8 units).
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_bwd_epi_kernel(StepArgsB p) {
+  const int H = p.H, B = p.B;
+  const int gpr = H / 8;
+  const long per_task = (long)B * gpr;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= per_task * p.ntask) return;
+  const int task = (int)(gid / per_task);
+  const long rem = gid - (long)task * per_task;
+  const int row = (int)(rem / gpr), j8 = (int)(rem - (long)row * gpr) * 8;
+  const StepTaskB& q = p.t[task];
+  float dh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* p0 = p.partial + ((long)(task * 2) * B + row) * H + j8;
+  if (q.A0) { float a[8]; load8<float>(p0, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dh[e] += a[e]; }
+  if (q.A1) { float a[8]; load8<float>(p0 + (long)B * H, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dh[e] += a[e]; }
+  bwd_cell_group<T>(p, q, row, j8, 8, true, dh);
 }
 
 // ---------------------------------------------------------------------------------------------- host drivers
@@ -497,7 +548,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + BJ - 1) / BJ; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
   const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (BJ == 64) ? 3 : (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
-  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + 4 * BJ) * KB;
+  size_t lds = (size_t)(nbuf > 0 ? nbuf : 2) * (BM + 4 * BJ) * KB;
   const size_t stage_bytes = (size_t)BM * 4 * (BJ + 4) * sizeof(float);     // epilogue staging tile
   if (lds < stage_bytes) lds = stage_bytes;
   for (int dd = 0; dd < T + NL - 1; ++dd) {
@@ -581,12 +632,21 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     if (d->dh_last[l] && !al16(d->dh_last[l])) vec = false;
     if (d->dh0[l] && !al16(d->dh0[l])) vec = false;
   }
+  // Split mode (bf16, whole 128 x 128 tiles): the hidden axis is only H wide, so fused tiles must be small (64 x 64) to fill the chip and
+  // each CU then streams (64+64) operand rows per 4096 outputs.  Splitting the contraction by SEGMENT across workgroups doubles the
+  // parallelism instead: 128 x 128 tiles move half the bytes per output; the fp32 partial tiles (2 x B x H per cell, L2-resident) are summed
+  // by a second, fully parallel element-wise launch that also does the gate-derivative math.
+  const int split_knob = tune_int("MVAE_BWD_SPLIT", 1);      // 0 = never, 1 = when it fills the chip, 2 = whenever the shape allows (tests)
+  const bool split = split_knob && dt == MVAE_BF16 && pipe && vec && B % 128 == 0 && H % 128 == 0 && d->split_ws &&
+                     d->split_ws_bytes >= (size_t)NL * 2 * B * H * sizeof(float) &&
+                     (split_knob == 2 || (long)(B / 128) * (H / 128) * 2 * NL >= 256);   // measured: B=512 56.8 vs 60.3 us, B=256 48.5 vs 45.4 us
+  if (split) { BM = 128; BN = 128; }
   StepArgsB a;
-  a.lengths = d->lengths; a.cell = d->cell;
+  a.lengths = d->lengths; a.cell = d->cell; a.split = split ? 1 : 0; a.partial = split ? reinterpret_cast<float*>(d->split_ws) : nullptr;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
   const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
-  size_t lds = (size_t)(nbuf ? nbuf : 2) * (BM + BN) * KB;
+  size_t lds = (size_t)(split ? 4 : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
   const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   bool want_dh0 = false;
@@ -626,7 +686,13 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * ldg, dt)); q.ldg = ldg;
     }
     a.ntask = n;
-    dim3 grid(n * a.tiles_m * a.tiles_n), block(256);
+    dim3 grid(n * a.tiles_m * a.tiles_n * (split ? 2 : 1)), block(256);
+    if (split) {
+      MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4>));
+      const long groups = (long)n * B * (H / 8);
+      hipLaunchKernelGGL((lstm_bwd_epi_kernel<bf16_t>), dim3((unsigned)((groups + 255) / 256)), block, 0, st, a);
+      continue;
+    }
 #define BWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<TT_, BM_, (BM_ == 32 ? 32 : 64), NB_>)); continue; }
     if (dt == MVAE_BF16) {
       BWD_CASE(bf16_t, 128, 0) BWD_CASE(bf16_t, 128, 3) BWD_CASE(bf16_t, 128, 4) BWD_CASE(bf16_t, 128, 5) BWD_CASE(bf16_t, 128, 6)

@@ -90,3 +90,4 @@ __device__ __forceinline__ void tile_gemm_segment(char* smem, RowA rowA, RowB ro
     cur ^= 1;
   }
 }
+

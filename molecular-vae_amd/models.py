@@ -464,7 +464,7 @@ class MolDecoder(nn.Module):
 
     def _side_stream(self, dev):
         if self.__dict__["_side"] is None:
-            self.__dict__["_side"] = torch.cuda.Stream(device=dev)
+            self.__dict__["_side"] = torch.cuda.Stream(device=dev)     # (stream priorities were measured: no effect here)
         return self.__dict__["_side"]
 
     def forward(self, x):

@@ -52,8 +52,8 @@ class Scratch:
     _bufs = {}
 
     @classmethod
-    def get(cls, nbytes, device):
-        key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
+    def get(cls, nbytes, device, tag=""):
+        key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0, tag)
         b = cls._bufs.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -286,6 +286,9 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     _fill(d.dstate, dstate)
     if dh0 is not None:
         _fill(d.dh0, dh0)
+    need = NL * 2 * B * H * 4                       # scratch of the split-segment schedule (used only when the shape qualifies)
+    sws = Scratch.get(need, dy.device if dy is not None else dG[0].device, tag="rnn_split")
+    d.split_ws, d.split_ws_bytes = sws.data_ptr(), need
     with _Timed(tag):
         check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr()), "mvae_rnn_bwd")
 

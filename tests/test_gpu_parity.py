@@ -150,6 +150,15 @@ def test_lstm_tile_variants_vs_oracle(env, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("split", ["0", "2"])
+def test_lstm_bwd_split_segment_schedule(split, monkeypatch):
+    """Backward with the contraction split by segment across workgroups (128x128 partial tiles + element-wise second launch) vs fused."""
+    monkeypatch.setenv("MVAE_BWD_SPLIT", split)
+    errs = _lstm_case(torch.bfloat16, 5, 256, 128, 3, 8)
+    bad = {k: v for k, v in errs.items() if v > 3e-2}
+    assert not bad, bad
+
+
 def test_small_ops_vs_oracle():
     rs = np.random.RandomState(3)
     B, Lq, C, o = 5, 11, 12, 16

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # sizes computed by hand from include/mvae.h (LP64): guards the ctypes mirror against drift
     assert ctypes.sizeof(L.RnnFwdDesc) == 7 * 4 + 4 + 8 * 4 + 8 * (8 * 4) + 8 * 8 + 8 * 8 + 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8
-    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3
+    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3 + 16
 
 
 def test_state_dict_keys_and_shapes_match_reference_layout():
