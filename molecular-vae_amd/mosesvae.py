@@ -96,6 +96,59 @@ class VAE(nn.Module):
         kl, _, z, logvar, _, _ = self.forward(x, eps)
         return z, kl, logvar
 
+    def sample_z_prior(self, n_batch):
+        """mosesvae.py:201-211 as intended (the reference reads an attribute it never sets): z ~ N(0, I)."""
+        return torch.randn(n_batch, self.d_z, device=self.device)
+
+    @torch.no_grad()
+    def sample(self, n_batch, max_len=100, z=None, temp=1.0, return_tokens=False):
+        """mosesvae.py:214-262 (autoregressive decoding, multinomial sampling at temperature `temp`) on the same GRU step kernels,
+        one wavefront launch per generated token.  Upstream bugs fixed: boolean masks, a real d_z.  Returns (list of strings, z)."""
+        dev = self.device
+        _require_cuda(dev, "mosesvae.VAE.sample")
+        P = self._pack(dev)
+        ws, dt, f32 = self._ws, self.compute_dtype, torch.float32
+        if z is None:
+            z = self.sample_z_prior(n_batch)
+        z = z.to(dev).float().contiguous()
+        B, V, dz = n_batch, self.x_emb.num_embeddings, self.d_z
+        pd = P["dec"]; Hd = pd["H"]; NL = self.decoder_rnn.num_layers
+        Vp, ldh = _pad(V, 4), Hd + _LDPAD
+        W = lambda name, shape, d=f32: ws.get("smp_" + name, shape, d, dev)
+        h0 = W("h0", (B, Hd)); ops.gemm_nt(z, self.decoder_lat.weight, h0, B, Hd, dz, bias=self.decoder_lat.bias)
+        tbl3 = W("tbl3", (V, 3 * Hd)); ops.gemm_nt(P["E_p"], pd["Wx_p"], tbl3, V, 3 * Hd, Vp)
+        tbl4 = W("tbl4", (V, 4 * Hd)); tbl4[:, :3 * Hd].copy_(tbl3)
+        zp3 = W("zp3", (B, 3 * Hd)); ops.gemm_nt(z, P["Wz"], zp3, B, 3 * Hd, dz)
+        zp4 = W("zp4", (B, 4 * Hd)); zp4[:, :3 * Hd].copy_(zp3)
+        hbuf = [W(f"h{l}", (2, B, ldh), dt) for l in range(NL)]        # [0] = previous state, [1] = new state (swapped every token)
+        for l in range(NL):
+            ops.cast_transpose(h0, B, Hd, dst=hbuf[l][0])
+        gates = [W(f"gates{l}", (1, B, 4 * Hd), dt) for l in range(NL)]
+        hstate = [W(f"hstate{l}", (2, B, Hd)) for l in range(NL)]
+        add = W("add", (1, B, 4 * Hd)); logits = W("logits", (B, V))
+        w = torch.full((B,), self.bos, dtype=torch.long, device=dev)
+        x = torch.full((B, max_len), self.pad, dtype=torch.long, device=dev)
+        x[:, 0] = self.bos
+        end_pads = torch.full((B,), max_len, dtype=torch.long, device=dev)
+        eos_mask = torch.zeros(B, dtype=torch.bool, device=dev)
+        cur = 0
+        for i in range(1, max_len):
+            ops.gather_rows_tb(w.view(B, 1), tbl4, add, B, 1, V, 4 * Hd, base=zp4)
+            ops.rnn_fwd(L.CELL_GRU, dt, 1, B, Hd, add, 0, pd["Wih"], [pd["ldw"]] * NL, pd["Whh"], [pd["ldw"]] * NL, pd["bias"],
+                        [h[1 - cur:2 - cur] for h in hbuf], ldh, None, gates, hstate, h0=[h[cur] for h in hbuf], ldh0=ldh)
+            ops.gemm_nt(hbuf[-1][1 - cur], P["Wfc"], logits, B, V, Hd, bias=self.decoder_fc.bias)
+            cur = 1 - cur
+            y = torch.softmax(logits / temp, dim=-1)                    # [B, V] sampling glue (mosesvae.py:245-247)
+            w = torch.multinomial(y, 1)[:, 0]
+            x[~eos_mask, i] = w[~eos_mask]
+            i_eos = ~eos_mask & (w == self.eos)
+            end_pads[i_eos] = i + 1
+            eos_mask = eos_mask | i_eos
+        xs, ends = x.cpu(), end_pads.cpu()
+        if return_tokens:                                                # raw id tensors (specials included), for tests / downstream scoring
+            return [xs[b, :ends[b]] for b in range(B)], z
+        return [self.tensor2string(xs[b, :ends[b]]) for b in range(B)], z
+
     # -- packed shadows
     def _pack(self, dev):
         params = self._plist()

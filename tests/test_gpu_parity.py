@@ -361,3 +361,31 @@ def test_moses_larger_batch_vs_oracle():
     rg = ref["grads_for"](0.5)
     bad = {k: rel(p_.grad.cpu().numpy(), rg[k]) for k, p_ in model.named_parameters() if rel(p_.grad.cpu().numpy(), rg[k]) > 8e-2}
     assert not bad, bad
+
+
+def test_moses_sample_greedy_matches_teacher_forced_logits(golden_dir):
+    """VAE.sample() drives the GRU kernels one token at a time (T=1 launches, state carried through h0): at near-zero temperature every
+    generated token must be the arg-max of the oracle's teacher-forced logits for the same latent and prefix."""
+    g, model, params = _moses_setup(golden_dir, torch.float32)
+    z = torch.from_numpy(g["z"].astype(np.float32)).to(dev)
+    torch.manual_seed(0)
+    toks, z_out = model.sample(6, max_len=12, z=z, temp=1e-4, return_tokens=True)
+    assert len(toks) == 6 and torch.equal(z_out.cpu(), z.cpu())
+    torch.manual_seed(0)
+    strings, _ = model.sample(6, max_len=12, z=z, temp=1e-4)
+    assert all(isinstance(s, str) for s in strings)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    checked = 0
+    for b, tk in enumerate(toks):
+        ids = tk.numpy().astype(np.int64)
+        assert ids[0] == model.bos
+        if len(ids) < 2:
+            continue
+        ref = O.moses_forward(p64, [ids], np.zeros((1, 160)), int(g["pad"]), want_grads=False, z_override=g["z"][b:b + 1])
+        logits = ref["y"][0]                                  # [T, V]: position i predicts token i+1
+        top2 = np.sort(logits, -1)[:, -2:]
+        for i in range(len(ids) - 1):
+            if top2[i, 1] - top2[i, 0] > 1e-3:                # skip numerical ties
+                assert int(logits[i].argmax()) == int(ids[i + 1]), (b, i)
+                checked += 1
+    assert checked >= 20
