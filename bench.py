@@ -136,14 +136,18 @@ def main():
     fwd_us = 1e3 * tag_ms.get("dec_lstm_fwd", float("nan")) / n_launch
     bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-    dom = "lstm_step_bwd_kernel" if tag_ms.get("dec_lstm_bwd", 0) >= tag_ms.get("dec_lstm_fwd", 0) else "lstm_step_fwd_kernel"
-    ach = (bwd_f / (bwd_us * 1e-6) if dom.startswith("lstm_step_bwd") else fwd_f / (fwd_us * 1e-6)) / 1e12
+    # Dominant SINGLE kernel (profiles/r01_v4_kernel_stats.csv): the forward wavefront step.  The backward step is two kernels per launch
+    # since the split-segment schedule (partial-tile GEMM + element-wise gate-derivative kernel), each smaller than the forward step;
+    # its pair time is reported alongside.
+    dom = "lstm_step_fwd_kernel"
+    ach = fwd_f / (fwd_us * 1e-6) / 1e12
+    ach_bwd = bwd_f / (bwd_us * 1e-6) / 1e12
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB -> bytes) on the same
     # kernel at the same shape, collected off-line with tests/bench_kernels.py and committed under profiles/ (bench.py cannot run
     # the profiler on itself); null when the shape differs from the profiled one
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_kernels_T16_B512.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_kernels_T16_B512.json")))
         if B == 512 and args.dtype == "bf16":
             for k, v in pm.items():
                 if dom.replace("_kernel", "") in k:
@@ -154,6 +158,7 @@ def main():
                     traffic=traffic,
                     launches_per_pass=n_launch, avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
                     flops_per_launch=dict(lstm_step_fwd=fwd_f, lstm_step_bwd=bwd_f),
+                    bwd_pair_tflops=round(ach_bwd, 2),
                     phase_ms={k: round(v, 3) for k, v in tag_ms.items()},
                     whole_step_tflops=round(flops_per_molecule() * B * args.steps / dt / 1e12 / world * world, 2))
 
