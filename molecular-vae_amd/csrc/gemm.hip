@@ -108,36 +108,42 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
 }
 
 // C[M,N] = A^T . B with A [K][lda], B [K][ldb] (bf16, K-major): the weight-gradient contraction (see tile_pipe.hpp, TN form).
-template <int NBUF>
-__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmArgs p) {
+template <int NBUF, int MI, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256) void gemm_tn_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  constexpr int BM = 32 * MI;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = wave >> 1, wn = wave & 1;
   const int ntile = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap(blockIdx.x, ntile);
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  const int m0 = tm * 128, n0 = tn * 128;
+  const int m0 = tm * BM, n0 = tn * 128;
   const int split = blockIdx.y;
   const long kbeg = (long)split * p.kper;
   const long kend = (kbeg + p.kper < (long)p.K) ? (kbeg + p.kper) : (long)p.K;
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  PipeSegTN s;
-  pipe_seg_tn_init(s, reinterpret_cast<const bf16_t*>(p.A) + kbeg * p.lda, p.lda, m0, reinterpret_cast<const bf16_t*>(p.B) + kbeg * p.ldb,
-                   p.ldb, n0, (int)(kend - kbeg), tid);
-  tile_gemm_pipe_tn<NBUF>(smem, s, wm, wn, acc, tid);
+  PipeSegTN<MI> s;
+  pipe_seg_tn_init<MI>(s, reinterpret_cast<const bf16_t*>(p.A) + kbeg * p.lda, p.lda, m0, reinterpret_cast<const bf16_t*>(p.B) + kbeg * p.ldb,
+                       p.ldb, n0, (int)(kend - kbeg), tid & 255);
+  if constexpr (WS) {
+    tile_gemm_ws_tn<NBUF, MI>(smem, s, wm, wn, acc, tid);
+    if (tid >= 256) return;                       // loader waves own no accumulators
+  } else {
+    tile_gemm_pipe_tn<NBUF, MI>(smem, s, wm, wn, acc, tid);
+  }
   const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = n0 + wn * 64 + j * 16 + lr;
       if (col >= p.N) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + lq * 4 + r;
+        const int row = m0 + wm * (16 * MI) + i * 16 + lq * 4 + r;
         if (row >= p.M) continue;
         float v = acc[i][j][r];
         if (p.splits > 1) {
@@ -240,8 +246,12 @@ int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, cons
 namespace {
 Plan make_plan_tn(int M, int N, int K) {
   Plan pl;
-  pl.bm = 128;
-  pl.tiles_m = (M + 127) / 128; pl.tiles_n = (N + 127) / 128;
+  // 256 x 128 tiles (half the operand bytes per output of 128 x 128) whenever they still give >= 128 tiles: split-K then fills the chip
+  const char* fe = getenv("MVAE_TN_BM");
+  const int force_bm = fe ? atoi(fe) : 0;
+  pl.bm = ((long)((M + 255) / 256) * ((N + 127) / 128) >= 128) ? 256 : 128;
+  if (force_bm == 128 || force_bm == 256) pl.bm = force_bm;
+  pl.tiles_m = (M + pl.bm - 1) / pl.bm; pl.tiles_n = (N + 127) / 128;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   long ksteps = (K + 63) / 64;
   if (ksteps < 1) ksteps = 1;
@@ -284,23 +294,39 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
     p.partial = reinterpret_cast<float*>(ws);
   }
-  dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(256);
-  // ring depth 4 (128 KiB); MVAE_NBUF_TN=3 (96 KiB, leaves room for a second workgroup of another stream on the CU) was measured: slower
-  static int nbuf_tn = getenv("MVAE_NBUF_TN") ? atoi(getenv("MVAE_NBUF_TN")) : 4;
+  dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits);
   static bool attr_set = false;
   if (!attr_set) {
-    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<4, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (nbuf_tn == 4) hipLaunchKernelGGL(gemm_tn_bf16_kernel<4>, grid, block, 4 * 32768, st, p);
-  else hipLaunchKernelGGL(gemm_tn_bf16_kernel<3>, grid, block, 3 * 32768, st, p);
+  const char* we = getenv("MVAE_TN_WS");
+  const bool wspec = we ? atoi(we) != 0 : true;      // loader / consumer wave specialisation (512-thread workgroups)
+  if (wspec) {
+    if (pl.bm == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 8, true>), grid, dim3(512), 3 * (32768 + 16384), st, p);
+    else {
+      const char* ne = getenv("MVAE_NBUF_TN");
+      const int nb = ne ? atoi(ne) : 4;
+      if (nb == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 4, true>), grid, dim3(512), 3 * 32768, st, p);
+      else if (nb == 5) {
+        static bool a5 = false;
+        if (!a5) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<5, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a5 = true; }
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<5, 4, true>), grid, dim3(512), 5 * 32768, st, p);
+      } else hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 4, true>), grid, dim3(512), 4 * 32768, st, p);
+    }
+  } else {
+    if (pl.bm == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 8, false>), grid, dim3(256), 3 * (32768 + 16384), st, p);   // 144 KiB ring
+    else hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 4, false>), grid, dim3(256), 4 * 32768, st, p);
+  }
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), block, 0, st, p);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
     MVAE_CHECK_HIP(hipGetLastError());
   }
   return MVAE_OK;

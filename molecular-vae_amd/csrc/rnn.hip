@@ -74,14 +74,17 @@ struct StepTaskF {
 struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_j, dbg, vec, cell; };
 
 // NBUF > 0: LDS-direct ring of that depth; NBUF == 0: generic register-staged loop (any shape)
-template <typename T, int BM, int BJ, int NBUF>
-__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
+// WS: 512 threads, waves 4-7 only load (tile_gemm_ws); everyone takes part in the epilogue
+template <typename T, int BM, int BJ, int NBUF, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF p) {
   constexpr bool PIPE = NBUF > 0;
+  constexpr int NTHR = WS ? 512 : 256;
+  static_assert(!WS || NBUF > 0, "wave specialisation needs the LDS-direct ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(BJ == 32 || BJ == 64, "hidden units per tile");
   constexpr int JS = BJ / 32;                  // 16-wide hidden sub-tiles per wave and gate
   constexpr int BN = 4 * BJ, WM = BM / 2, MI = WM / 16, NI = 4 * JS;     // acc[mi][g * JS + s]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wj = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = wave >> 1, wj = wave & 1;
   const int per_task = p.tiles_m * p.tiles_j;
   const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task);
   const int task = bid / per_task;
@@ -103,15 +106,16 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
       const uint32_t lda = (uint32_t)q.lda0 * sz, ldw = (uint32_t)q.ldw0 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
-      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)(4 * H) * ldw, offA, offB, q.K0, tid);
+      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)(4 * H) * ldw, offA, offB, q.K0, tid & 255);
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
-      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)(4 * H) * ldw, offA, offB, q.K1, tid);
+      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)(4 * H) * ldw, offA, offB, q.K1, tid & 255);
     }
-    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), JS, BJ>(smem, s0, s1, wm * WM, wj * (BJ / 2), acc, tid);
+    if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), JS, BJ>(smem, s0, s1, wm * WM, wj * (BJ / 2), acc, tid);
+    else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), JS, BJ>(smem, s0, s1, wm * WM, wj * (BJ / 2), acc, tid);
   } else {
     int brow[NI];
 #pragma unroll
@@ -135,10 +139,39 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
   }
   if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.c_out[0] = 1.f; return; }   // tuning hook: main loop only
 
-  // ---- epilogue: accumulators -> LDS [row][gate][BJ + 4] (fp32), then one thread per (row, 8 hidden units)
+  // ---- epilogue: accumulators -> LDS [row][gate][BJ + 4] (fp32), then one thread per (row, 8 hidden units).
+  // Everything the gate math reads from global memory (bias, previous state) is requested BEFORE the staging writes and the
+  // barrier, for all of the thread's rows at once, so one load latency is exposed instead of one per row.
   constexpr int SJ = BJ + 4;
+  constexpr int GPRW = BJ / 8;                 // 8-unit groups per tile row
+  constexpr int NIT = (BM * GPRW + NTHR - 1) / NTHR;
   float* stg = reinterpret_cast<float*>(smem);
-  {
+  const int g8 = tid % GPRW;                   // constant per thread
+  const int j8 = j0 + g8 * 8;
+  const int n = (H - j8 < 8) ? (H - j8) : 8;   // <= 0: this thread's units are outside the layer
+  const bool vec = p.vec != 0;
+  float bias[4][8], cpv[NIT][8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (q.bias && n > 0) ldn<float>(q.bias + g * H + j8, bias[g], n, vec);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias[g][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int lrow = tid / GPRW + it * (NTHR / GPRW);
+    const int row = m0 + lrow;
+    const bool live = n > 0 && lrow < BM && row < B;
+    if (live && q.c_prev) ldn<float>(q.c_prev + (long)row * H + j8, cpv[it], n, vec);
+    else if (live && q.hprev_t0) ldn<T>(reinterpret_cast<const T*>(q.hprev_t0) + (long)row * q.lda1 + j8, cpv[it], n, vec);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cpv[it][e] = 0.f;
+    }
+  }
+  if (!WS || tid < 256) {
     const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -151,27 +184,13 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
         }
   }
   __syncthreads();
-  constexpr int GPRW = BJ / 8;                 // 8-unit groups per tile row
-  const int g8 = tid % GPRW;                   // constant per thread
-  const int j8 = j0 + g8 * 8;
-  if (j8 >= H) return;
-  const int n = (H - j8 < 8) ? (H - j8) : 8;
-  const bool vec = p.vec != 0;
-  float bias[4][8];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (q.bias) ldn<float>(q.bias + g * H + j8, bias[g], n, vec);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bias[g][e] = 0.f;
-    }
-  }
+  if (n <= 0) return;
   T* hout = reinterpret_cast<T*>(q.h_out);
   T* gout = reinterpret_cast<T*>(q.g_out);
   T* csave = reinterpret_cast<T*>(q.c_save);
 #pragma unroll
-  for (int it = 0; it < (BM * GPRW + 255) / 256; ++it) {
-    const int lrow = tid / GPRW + it * (256 / GPRW);
+  for (int it = 0; it < NIT; ++it) {
+    const int lrow = tid / GPRW + it * (NTHR / GPRW);
     const int row = m0 + lrow;
     if (lrow >= BM || row >= B) continue;
     float pre[4][8];
@@ -191,13 +210,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgsF p) {
         for (int e = 0; e < 8; ++e) pre[g][e] += a[e];
       }
     }
-    float cp[8];
-    if (q.c_prev) ldn<float>(q.c_prev + (long)row * H + j8, cp, n, vec);
-    else if (q.hprev_t0) ldn<T>(reinterpret_cast<const T*>(q.hprev_t0) + (long)row * q.lda1 + j8, cp, n, vec);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cp[e] = 0.f;
-    }
+    const float (&cp)[8] = cpv[it];
     T* g4 = gout + (long)row * 4 * H + j8;
     if (p.cell == MVAE_CELL_LSTM) {
       float gi[8], gf[8], gg[8], go[8], c[8], h[8];
@@ -336,12 +349,14 @@ __device__ __forceinline__ void bwd_cell_group(const StepArgsB& p, const StepTas
   }
 }
 
-template <typename T, int BM, int BN, int NBUF>
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
+template <typename T, int BM, int BN, int NBUF, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB p) {
   constexpr bool PIPE = NBUF > 0;
+  constexpr int NTHR = WS ? 512 : 256;
+  static_assert(!WS || NBUF > 0, "wave specialisation needs the LDS-direct ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = wave >> 1, wn = wave & 1;
   const int per_task = p.tiles_m * p.tiles_n;
   const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task * (p.split ? 2 : 1));
   const int task2 = bid / per_task;
@@ -366,17 +381,18 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
       const uint32_t lda = (uint32_t)q.lda0 * sz, ldw = (uint32_t)q.ldw0 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
-      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)H * ldw, offA, offB, q.K0, tid);
+      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)H * ldw, offA, offB, q.K0, tid & 255);
       if (p.split && seg == 1) s0.nk = 0;
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
-      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, q.K1, tid);
+      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, q.K1, tid & 255);
       if (p.split && seg == 0) s1.nk = 0;
     }
-    tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
   } else {
     int brow[NI];
 #pragma unroll
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
   // ---- epilogue: dh tile -> LDS [row][BN + 4] (fp32), then one thread per (row, 8 hidden units)
   constexpr int SN = BN + 4;
   float* stg = reinterpret_cast<float*>(smem);
-  {
+  if (!WS || tid < 256) {
     const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -423,8 +439,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
     // split mode (host guarantees whole tiles and the vector path): store this segment's fp32 partial tile; lstm_bwd_epi_kernel sums
     float* part = p.partial + ((long)(task * 2 + seg) * B) * H;
 #pragma unroll
-    for (int it = 0; it < (BM * GPR + 255) / 256; ++it) {
-      const int lrow = tid / GPR + it * (256 / GPR);
+    for (int it = 0; it < (BM * GPR + NTHR - 1) / NTHR; ++it) {
+      const int lrow = tid / GPR + it * (NTHR / GPR);
       const int row = m0 + lrow;
       if (lrow >= BM || row >= B) continue;
       const float* sp = stg + lrow * SN + g8 * 8;
@@ -435,8 +451,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgsB p) {
     return;
   }
 #pragma unroll
-  for (int it = 0; it < (BM * GPR + 255) / 256; ++it) {
-    const int lrow = tid / GPR + it * (256 / GPR);
+  for (int it = 0; it < (BM * GPR + NTHR - 1) / NTHR; ++it) {
+    const int lrow = tid / GPR + it * (NTHR / GPR);
     const int row = m0 + lrow;
     if (lrow >= BM || row >= B) continue;
     float dh[8];
@@ -548,6 +564,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + BJ - 1) / BJ; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
   const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (BJ == 64) ? 3 : (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
+  const bool ws = tune_int("MVAE_WS_FWD", 1) != 0;      // loader / consumer wave specialisation for the wide tile
   size_t lds = (size_t)(nbuf > 0 ? nbuf : 2) * (BM + 4 * BJ) * KB;
   const size_t stage_bytes = (size_t)BM * 4 * (BJ + 4) * sizeof(float);     // epilogue staging tile
   if (lds < stage_bytes) lds = stage_bytes;
@@ -582,7 +599,11 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_j), block(256);
 #define FWD_CASE(TT_, BM_, NB_) if (BJ == 32 && BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
-    if (BJ == 64 && nbuf == 3) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3>)); continue; }
+    if (BJ == 64 && nbuf == 3) {
+      if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3, true>)); }
+      else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3>));
+      continue;
+    }
     if (dt == MVAE_BF16) {
       FWD_CASE(bf16_t, 128, 0) FWD_CASE(bf16_t, 128, 3) FWD_CASE(bf16_t, 128, 4) FWD_CASE(bf16_t, 128, 5)
       FWD_CASE(bf16_t, 64, 0) FWD_CASE(bf16_t, 64, 3) FWD_CASE(bf16_t, 64, 4) FWD_CASE(bf16_t, 64, 5)
@@ -646,6 +667,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
   a.dbg = tune_int("MVAE_DBG", 0);
   const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
+  const bool ws = tune_int("MVAE_WS_BWD", 1) != 0;      // loader / consumer wave specialisation of the split-mode GEMM kernel
   size_t lds = (size_t)(split ? 4 : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
   const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
@@ -688,7 +710,8 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n * (split ? 2 : 1)), block(256);
     if (split) {
-      MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4>));
+      if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true>)); block = dim3(256); }
+      else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4>));
       const long groups = (long)n * B * (H / 8);
       hipLaunchKernelGGL((lstm_bwd_epi_kernel<bf16_t>), dim3((unsigned)((groups + 255) / 256)), block, 0, st, a);
       continue;

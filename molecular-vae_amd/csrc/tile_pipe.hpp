@@ -184,20 +184,26 @@ template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr64(uint32_t addr)
   return v;
 }
 
-struct PipeSegTN {
+// Tile = (32*MI) x 128 (MI = 4: 128 x 128, MI = 8: 256 x 128); 4 waves as 2 (m) x 2 (n), wave tile (16*MI) x 64.
+// Stage = 64 k-rows of A (row = 64*MI bytes) followed by 64 k-rows of B (256-byte rows).
+template <int MI> struct PipeSegTN {
   __amdgpu_buffer_rsrc_t ra, rb;
-  uint32_t offA[4], offB[4];       // per-thread byte offsets of its 4 + 4 LDS-DMA pieces at k-step 0
+  uint32_t offA[MI], offB[4];      // per-thread byte offsets of its MI + 4 LDS-DMA pieces (1 KiB per wave instruction) at k-step 0
   uint32_t kstepA, kstepB;         // bytes per 64-row K-step
   int nk;
 };
 
 __device__ __forceinline__ uint32_t tn_f(int krow) { return (uint32_t)((krow & 3) | (((krow >> 3) & 1) << 2)); }
 
-// A: [K][lda] elements (bf16), tile columns [m0, m0+128); B likewise with n0.  K rows beyond the matrix read as zero
+// A: [K][lda] elements (bf16), tile columns [m0, m0 + 32*MI); B likewise with [n0, n0 + 128).  K rows beyond the matrix read as zero
 // through the descriptor bound (num_records = K * ld * 2).
-__device__ __forceinline__ void pipe_seg_tn_init(PipeSegTN& s, const void* A, long lda, int m0, const void* B, long ldb, int n0,
+template <int MI>
+__device__ __forceinline__ void pipe_seg_tn_init(PipeSegTN<MI>& s, const void* A, long lda, int m0, const void* B, long ldb, int n0,
                                                  int K, int tid) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int RA = 64 * MI;                    // bytes per A tile row
+  constexpr int RPP = 1024 / RA;                 // A k-rows per 1-KiB piece (4 or 2)
+  constexpr int CPR = RA / 16;                   // 16-byte chunks per A row (16 or 32)
   s.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A), 0, (int)((long)K * lda * 2), 0x00020000);
   s.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(B), 0, (int)((long)K * ldb * 2), 0x00020000);
   s.nk = (K + 63) / 64;
@@ -205,50 +211,61 @@ __device__ __forceinline__ void pipe_seg_tn_init(PipeSegTN& s, const void* A, lo
   s.kstepB = (uint32_t)(64 * ldb * 2);
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ii = i * 4 + wave;                 // 1-KiB piece index inside the operand's 16-KiB stage half
-    const int krow = ii * 4 + (lane >> 4), pc = lane & 15;
-    const uint32_t lc = (uint32_t)((((pc >> 1) ^ tn_f(krow)) << 1) | (pc & 1));   // logical 16-byte chunk fetched into physical chunk pc
+  for (int i = 0; i < MI; ++i) {
+    const int ii = i * 4 + wave;                 // piece index inside the A part of the stage
+    const int krow = ii * RPP + lane / CPR, pc = lane % CPR;
+    // physical 16-byte chunk pc holds logical chunk lc: the low 3 bits of the 32-byte block index are XOR-ed with f(k)
+    const uint32_t lc = (uint32_t)((((pc >> 1) ^ tn_f(krow)) << 1) | (pc & 1));
     s.offA[i] = (uint32_t)krow * (uint32_t)(lda * 2) + (uint32_t)(m0 * 2) + lc * 16u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ii = i * 4 + wave;
+    const int krow = ii * 4 + (lane >> 4), pc = lane & 15;
+    const uint32_t lc = (uint32_t)((((pc >> 1) ^ tn_f(krow)) << 1) | (pc & 1));
     s.offB[i] = (uint32_t)krow * (uint32_t)(ldb * 2) + (uint32_t)(n0 * 2) + lc * 16u;
   }
 #endif
 }
 
-template <int NBUF>
-__device__ __forceinline__ void pipe_tn_issue(char* smem, const PipeSegTN& s, int st, int wave) {
+template <int NBUF, int MI>
+__device__ __forceinline__ void pipe_tn_issue(char* smem, const PipeSegTN<MI>& s, int st, int wave) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  char* stage = smem + (st % NBUF) * 32768;
+  constexpr int ABYTES = 64 * 64 * MI, STAGE = ABYTES + 16384;
+  char* stage = smem + (st % NBUF) * STAGE;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     lds_void_t* dst = (lds_void_t*)(stage + (i * 4 + wave) * 1024);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + (uint32_t)st * s.kstepA, 0, 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    lds_void_t* dst = (lds_void_t*)(stage + 16384 + (i * 4 + wave) * 1024);
+    lds_void_t* dst = (lds_void_t*)(stage + ABYTES + (i * 4 + wave) * 1024);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + (uint32_t)st * s.kstepB, 0, 0, 0);
   }
 #endif
 }
 
-template <int I, int N> struct FragReadTN {   // fragment I of N: two transposed reads (k rows 8g..8g+3 and 8g+4..8g+7)
+// fragment I of N: two transposed reads (k rows 8g..8g+3 and 8g+4..8g+7); ROWB = bytes per tile row
+template <int I, int N, int ROWB> struct FragReadTN {
   template <int KOFF>
   static __device__ __forceinline__ void run(u32x4 (&dst)[N], const uint32_t (&addr)[N], uint32_t st) {
     const u32x2 lo = lds_read_tr64<KOFF>(st + addr[I]);
-    const u32x2 hi = lds_read_tr64<KOFF + 1024>(st + addr[I]);
+    const u32x2 hi = lds_read_tr64<KOFF + 4 * ROWB>(st + addr[I]);
     dst[I] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-    FragReadTN<I + 1, N>::template run<KOFF>(dst, addr, st);
+    FragReadTN<I + 1, N, ROWB>::template run<KOFF>(dst, addr, st);
   }
 };
-template <int N> struct FragReadTN<N, N> {
+template <int N, int ROWB> struct FragReadTN<N, N, ROWB> {
   template <int KOFF> static __device__ __forceinline__ void run(u32x4 (&)[N], const uint32_t (&)[N], uint32_t) {}
 };
 
-// 128 x 128 tile, 4 waves (2 x 2), wave tile 64 x 64 (MI = NI = 4).  smem: NBUF * 32 KiB.
-template <int NBUF>
-__device__ __forceinline__ void tile_gemm_pipe_tn(char* smem, const PipeSegTN& s, int wm, int wn, f32x4 (&acc)[4][4], int tid) {
-  constexpr int LPS = 8;
+// smem: NBUF * (4096*MI + 16384) bytes.
+template <int NBUF, int MI>
+__device__ __forceinline__ void tile_gemm_pipe_tn(char* smem, const PipeSegTN<MI>& s, int wm, int wn, f32x4 (&acc)[MI][4], int tid) {
+  constexpr int LPS = MI + 4;
+  constexpr int RA = 64 * MI, ABYTES = 64 * RA, STAGE = ABYTES + 16384;
+  static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = s.nk;
@@ -256,39 +273,178 @@ __device__ __forceinline__ void tile_gemm_pipe_tn(char* smem, const PipeSegTN& s
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const uint32_t f = (uint32_t)(q | ((g & 1) << 2));
-  uint32_t addrA[4], addrB[4];
+  uint32_t addrA[MI], addrB[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    addrA[i] = (uint32_t)(8 * g + q) * 256u + ((((uint32_t)(wm * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u;
-    addrB[i] = (uint32_t)(8 * g + q) * 256u + ((((uint32_t)(wn * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u + 16384u;
-  }
+  for (int i = 0; i < MI; ++i) addrA[i] = (uint32_t)(8 * g + q) * (uint32_t)RA + ((((uint32_t)(wm * MI + i)) ^ f) << 5) + (uint32_t)pp * 8u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) addrB[i] = (uint32_t)(8 * g + q) * 256u + ((((uint32_t)(wn * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u + (uint32_t)ABYTES;
 #pragma unroll
   for (int st = 0; st < NBUF - 1; ++st)
-    if (st < nk) pipe_tn_issue<NBUF>(smem, s, st, wave);
+    if (st < nk) pipe_tn_issue<NBUF, MI>(smem, s, st, wave);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + NBUF - 1 < nk) pipe_tn_issue<NBUF>(smem, s, kt + NBUF - 1, wave);
-    const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * 32768);
-    u32x4 a0[4], b0[4], a1[4], b1[4];
-    FragReadTN<0, 4>::run<0>(a0, addrA, st);          // k rows 0..31 of the stage
-    FragReadTN<0, 4>::run<0>(b0, addrB, st);
+    if (kt + NBUF - 1 < nk) pipe_tn_issue<NBUF, MI>(smem, s, kt + NBUF - 1, wave);
+    const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
+    u32x4 a0[MI], b0[4], a1[MI], b1[4];
+    FragReadTN<0, MI, RA>::template run<0>(a0, addrA, st);          // k rows 0..31 of the stage
+    FragReadTN<0, 4, 256>::template run<0>(b0, addrB, st);
     wait_lgkmcnt<0>();
-    FragReadTN<0, 4>::run<8192>(a1, addrA, st);       // k rows 32..63: in flight under the first 16 MFMAs
-    FragReadTN<0, 4>::run<8192>(b1, addrB, st);
+    FragReadTN<0, MI, RA>::template run<32 * RA>(a1, addrA, st);    // k rows 32..63: in flight under the first MFMAs
+    FragReadTN<0, 4, 256>::template run<32 * 256>(b1, addrB, st);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
     wait_lgkmcnt<0>();
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         mma16<bf16_t>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
   }
   __builtin_amdgcn_s_barrier();
+}
+
+// =====================================================================================================================
+// Wave-specialised main loops (512-thread workgroups): waves 0-3 are CONSUMERS (fragment reads + MFMA only), waves 4-7 are
+// LOADERS (LDS-DMA issue + counted vmcnt only).  An LDS-DMA piece costs its issuing wave ~60-180 cycles of issue time; with
+// one wave per SIMD doing both jobs those cycles come straight out of the MFMA stream.  With a loader wave beside every
+// consumer wave on each SIMD the MFMA stream only stops for data.  One s_barrier per K-step carries both hand-offs:
+// barrier(kt) = "stage kt has landed" (loaders waited for it) + "nobody still reads stage kt-1" (consumers drained lgkmcnt).
+// The consumers are software-pipelined across the barrier: the first half of stage kt+1 is read under the MFMAs of the second
+// half of stage kt, so no fragment-read latency is exposed after the prologue.
+// =====================================================================================================================
+__device__ __forceinline__ void ws_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NBUF, int MI>
+__device__ __forceinline__ void tile_gemm_ws_tn(char* smem, const PipeSegTN<MI>& s, int wm, int wn, f32x4 (&acc)[MI][4], int tid) {
+  constexpr int LPS = MI + 4;
+  constexpr int RA = 64 * MI, ABYTES = 64 * RA, STAGE = ABYTES + 16384;
+  static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = s.nk;
+  if (nk <= 0) return;
+  if (wave >= 4) {
+    // ---- loader
+#pragma unroll
+    for (int st = 0; st < NBUF - 1; ++st)
+      if (st < nk) pipe_tn_issue<NBUF, MI>(smem, s, st, wave - 4);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>();
+      else wait_vmcnt<0>();
+      ws_barrier();                                                       // barrier(kt)
+      if (kt + NBUF - 1 < nk) pipe_tn_issue<NBUF, MI>(smem, s, kt + NBUF - 1, wave - 4);
+    }
+  } else {
+    // ---- consumer
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const uint32_t f = (uint32_t)(q | ((g & 1) << 2));
+    uint32_t addrA[MI], addrB[4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) addrA[i] = (uint32_t)(8 * g + q) * (uint32_t)RA + ((((uint32_t)(wm * MI + i)) ^ f) << 5) + (uint32_t)pp * 8u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) addrB[i] = (uint32_t)(8 * g + q) * 256u + ((((uint32_t)(wn * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u + (uint32_t)ABYTES;
+    u32x4 a0[MI], b0[4], a1[MI], b1[4];
+    ws_barrier();                                                         // barrier(0)
+    FragReadTN<0, MI, RA>::template run<0>(a0, addrA, lds0);
+    FragReadTN<0, 4, 256>::template run<0>(b0, addrB, lds0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
+      wait_lgkmcnt<0>();                                                  // first half of stage kt (issued under the previous MFMAs)
+      FragReadTN<0, MI, RA>::template run<32 * RA>(a1, addrA, st);
+      FragReadTN<0, 4, 256>::template run<32 * 256>(b1, addrB, st);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
+      wait_lgkmcnt<0>();                                                  // second half: every read of stage kt is done
+      if (kt + 1 < nk) {
+        ws_barrier();                                                     // barrier(kt + 1)
+        const uint32_t sn = lds0 + (uint32_t)(((kt + 1) % NBUF) * STAGE);
+        FragReadTN<0, MI, RA>::template run<0>(a0, addrA, sn);
+        FragReadTN<0, 4, 256>::template run<0>(b0, addrB, sn);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          mma16<bf16_t>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
+    }
+  }
+  ws_barrier();
+}
+
+// NT form of the wave-specialised loop (same contract as tile_gemm_pipe, 512 threads; s0 / s1 must have been initialised
+// with tid & 255, so that loader wave w + 4 issues the pieces wave w issues in the 256-thread form).
+template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT>
+__device__ __forceinline__ void tile_gemm_ws(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int arow0, int brow0,
+                                             f32x4 (&acc)[MI][NI], int tid) {
+  constexpr int STAGE = (BM + BN) * KB;
+  constexpr int LPS = (BM + BN) * 8 / 256;
+  static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
+  static_assert(MI + NI <= 15, "lgkmcnt range");
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = s0.nk + s1.nk;
+  if (nk <= 0) return;
+  if (wave >= 4) {
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+      if (s < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, s, wave - 4);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>();
+      else wait_vmcnt<0>();
+      ws_barrier();                                                       // barrier(kt)
+      if (kt + NBUF - 1 < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, wave - 4);
+    }
+  } else {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    const int lr = lane & 15, lk = lane >> 4;
+    uint32_t a_lane[2], b_lane[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      a_lane[kk] = (uint32_t)swz(arow0 + lr, kk * 4 + lk);
+      b_lane[kk] = (uint32_t)swz(brow0 + lr, kk * 4 + lk) + BM * KB;
+    }
+    u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
+    ws_barrier();                                                         // barrier(0)
+    FragRead<0, MI, 16 * KB>::run(a0, lds0 + a_lane[0]);
+    FragReadB<0, NI, JS, BOUT>::run(b0, lds0 + b_lane[0]);
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
+      FragRead<0, MI, 16 * KB>::run(a1, st + a_lane[1]);
+      FragReadB<0, NI, JS, BOUT>::run(b1, st + b_lane[1]);
+      wait_lgkmcnt<MI + NI>();                                            // first half arrived, second half in flight
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          mma16<T>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
+      wait_lgkmcnt<0>();                                                  // every read of stage kt is done
+      if (kt + 1 < nk) {
+        ws_barrier();                                                     // barrier(kt + 1)
+        const uint32_t sn = lds0 + (uint32_t)(((kt + 1) % NBUF) * STAGE);
+        FragRead<0, MI, 16 * KB>::run(a0, sn + a_lane[0]);
+        FragReadB<0, NI, JS, BOUT>::run(b0, sn + b_lane[0]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          mma16<T>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
+    }
+  }
+  ws_barrier();
 }

@@ -123,6 +123,14 @@ def test_gemm_tn_bf16(shape):
     assert rel(out.cpu().numpy(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("bm", ["128", "256"])
+@pytest.mark.parametrize("shape", [(300, 200, 513), (4096 + 35, 1024, 200), (256, 128, 64)])
+def test_gemm_tn_bf16_tile_variants(shape, bm, monkeypatch):
+    """Both TN tiles (128 x 128 and 256 x 128) on ragged shapes, forced through MVAE_TN_BM."""
+    monkeypatch.setenv("MVAE_TN_BM", bm)
+    test_gemm_tn_bf16(shape)
+
+
 @pytest.mark.parametrize("case", [
     (torch.float32, 7, 5, 32, 2, 16, 2e-5),       # tiny, generic register-staged path
     (torch.bfloat16, 7, 5, 32, 2, 16, 3e-2),
