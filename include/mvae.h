@@ -175,23 +175,30 @@ size_t mvae_colsum_t_workspace(int M, int N);
 int mvae_colsum_t(int dtype, int M, int N, const void* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
- * Conv1d(k) + bias + SELU, valid, stride 1 (K3; models.py:71-77 ConvSELU, :118-120, :129-131) as an
- * im2col + MFMA GEMM with fused bias+SELU.  Input addressed by strides so the LSTM's time-major output can
- * be consumed in place:  x[b, ci, w] = x[b*sb + ci*sc + w*sw].  Output y[(b*Wout + w), co] (ldy).
- * col: scratch [B*Wout, Cin*k] fp32, kept for the backward pass.
+ * Conv1d(k) + bias + SELU, valid, stride 1 (K3; models.py:71-77 ConvSELU, :118-120, :129-131) as a
+ * sliding-window MFMA GEMM (exact f32).  Activations are CHANNELS-LAST with padded channel count:
+ *   x[b, w, c] = x[b * x_bs + w * ldx + c],  c < Cin valid, channels [Cin, ldx) must be zero;
+ *   y[b, w, o] = y[(b * Wout + w) * ldy + o], Wout = W - k + 1 (columns [Cout, ldy) are not written).
+ * The im2col row of (b, w) is the contiguous range x[b, w : w+k, :], so no im2col matrix exists; weights are
+ * repacked per step by mvae_conv1d_pack_weights:
+ *   wp [Cout][k * ldx]: wp[o][j * ldx + c] = w[o][c][j]          (forward / weight gradient; pads zero)
+ *   wq [Cin][k * ldo] : wq[c][j * ldo + o] = w[o][c][k - 1 - j]  (input gradient; pads zero)      either may be NULL.
+ * The LDS-direct main loop needs k * ldx (forward) / k * ldo (input gradient) to be a multiple of 32; other
+ * sizes run on the generic loop.
  */
-size_t mvae_conv1d_selu_fwd_workspace(int B, int Cin, int W, int Cout, int k);
-int mvae_conv1d_selu_fwd(int B, int Cin, int W, int Cout, int k, const float* x, int64_t sb, int64_t sc, int64_t sw,
-                         const float* w /* [Cout, Cin*k] */, const float* bias, float* col, float* y, int64_t ldy,
+int mvae_conv1d_pack_weights(int Cin, int Cout, int k, const float* w /* [Cout, Cin, k] */, int ldx, float* wp, int ldo, float* wq,
+                             void* stream);
+size_t mvae_conv1d_selu_fwd_workspace(int B, int W, int ldx, int Cout, int k);
+int mvae_conv1d_selu_fwd(int B, int W, int ldx, int64_t x_bs, int Cout, int k, const float* x, const float* wp, const float* bias,
+                         float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+/* dy, y: [B * Wout, ldo] (gradient w.r.t. y / forward output; ldo % 4 == 0), x: the forward input (ldx % 4 == 0, x_bs % 4 == 0).
+ * dzp: scratch [B, Wout + 2(k-1), ldo] -- receives the zero-padded pre-activation gradient.
+ * dw [Cout, Cin, k] and db [Cout] in the reference's parameter layout; dx [B * W, lddx] channels-last (NULL: not needed; else wq required).
+ * All pointers 16-byte aligned.  ws: scratch >= mvae_conv1d_selu_bwd_workspace bytes. */
+size_t mvae_conv1d_selu_bwd_workspace(int B, int W, int Cin, int ldx, int Cout, int ldo, int k);
+int mvae_conv1d_selu_bwd(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
+                         const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                          void* ws, size_t ws_bytes, void* stream);
-/* dy [B*Wout, Cout] (gradient w.r.t. y; overwritten with the pre-activation gradient), y: forward output.
- * dw [Cout, Cin*k], db [Cout], dx written with the same strides as x was read (dx_sb, dx_sc, dx_sw).
- * wT [Cin*k, ldwT] transposed weights (ldwT >= Cout; Cout must be a multiple of 4);
- * ws: scratch >= mvae_conv1d_selu_bwd_workspace bytes. */
-size_t mvae_conv1d_selu_bwd_workspace(int B, int Cin, int W, int Cout, int k);
-int mvae_conv1d_selu_bwd(int B, int Cin, int W, int Cout, int k, float* dy, int64_t lddy, const float* y, int64_t ldy,
-                         const float* col, const float* wT, int64_t ldwT, float* dw, float* db,
-                         float* dx, int64_t dx_sb, int64_t dx_sc, int64_t dx_sw, void* ws, size_t ws_bytes, void* stream);
 
 /* dpre = dy * SELU'(pre) expressed through the forward OUTPUT y (in place on dy).  models.py:58-68. */
 int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream);

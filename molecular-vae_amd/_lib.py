@@ -72,11 +72,11 @@ SIGNATURES = {
     "mvae_colsum": (_i, [_i, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
     "mvae_colsum_t_workspace": (_sz, [_i, _i]),
     "mvae_colsum_t": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "mvae_conv1d_pack_weights": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "mvae_conv1d_selu_fwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
-    "mvae_conv1d_selu_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
-    "mvae_conv1d_selu_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
-    "mvae_conv1d_selu_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64,
-                                  _vp, _sz, _vp]),
+    "mvae_conv1d_selu_fwd": (_i, [_i, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "mvae_conv1d_selu_bwd_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "mvae_conv1d_selu_bwd": (_i, [_i, _i, _i, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "mvae_selu_bwd": (_i, [_i64, _vp, _vp, _vp]),
     "mvae_lambda_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvae_lambda_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1,5 +1,5 @@
 // HBM-bound helper kernels of the SMILES-VAE training path (gfx950): casts/transposes, embedding-table gather and
-// its deterministic scatter, im2col/col2im, SELU derivative, reparameterisation, softmax head, ELBO, reductions,
+// its deterministic scatter, SELU derivative, reparameterisation, softmax head, ELBO, reductions,
 // gradient-norm + Adam.  All reductions use fixed orders (wave shuffle -> LDS -> serial over blocks) so results
 // are bitwise reproducible run to run.
 #include "common.hpp"
@@ -107,33 +107,6 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial,
   red[slot][e] = v;
   __syncthreads();
   if (slot == 0 && i < n) out[i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-}
-
-// ------------------------------------------------------------------------------------------- im2col / col2im
-// col[(b*Wout + w), ci*k + kk] = x[b*sb + ci*sc + (w+kk)*sw]
-__global__ __launch_bounds__(256) void im2col_kernel(int B, int Cin, int W, int k, const float* x, long sb, long sc, long sw, float* col) {
-  const int Wout = W - k + 1;
-  const long K = (long)Cin * k, n = (long)B * Wout * K;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const long row = i / K; const int kc = (int)(i - row * K);
-    const int b = (int)(row / Wout), w = (int)(row - (long)b * Wout);
-    const int ci = kc / k, kk = kc - ci * k;
-    col[i] = x[(long)b * sb + (long)ci * sc + (long)(w + kk) * sw];
-  }
-}
-// dx[b, ci, p] = sum_{kk} dcol[(b*Wout + p-kk), ci*k + kk]  for 0 <= p-kk < Wout  (gather form: deterministic)
-__global__ __launch_bounds__(256) void col2im_kernel(int B, int Cin, int W, int k, const float* dcol, float* dx, long sb, long sc, long sw) {
-  const int Wout = W - k + 1;
-  const long K = (long)Cin * k, n = (long)B * Cin * W;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int p = (int)(i % W); const long bc = i / W; const int ci = (int)(bc % Cin); const int b = (int)(bc / Cin);
-    float v = 0.f;
-    for (int kk = 0; kk < k; ++kk) {
-      const int w = p - kk;
-      if (w >= 0 && w < Wout) v += dcol[((long)b * Wout + w) * K + (long)ci * k + kk];
-    }
-    dx[(long)b * sb + (long)ci * sc + (long)p * sw] = v;
-  }
 }
 
 // out[n, b, a] = in[n, a, b]   (batched 2-D transpose; flatten order of models.py:6-10 <-> GEMM row order)
@@ -671,62 +644,6 @@ int mvae_ce_loss_bwd(int dtype, int B, int T, int V, const float* logits, int64_
 int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream) {
   if (!dy || !y) return MVAE_ERR_INVALID;
   return launch_selu_bwd(n, dy, y, (hipStream_t)stream);
-}
-
-// ---- conv1d + SELU (models.py:71-77, 118-120, 129-131)
-size_t mvae_conv1d_selu_fwd_workspace(int B, int Cin, int W, int Cout, int k) {
-  return gemm_nt_workspace_bytes(B * (W - k + 1), Cout, Cin * k, MVAE_F32);
-}
-int mvae_conv1d_selu_fwd(int B, int Cin, int W, int Cout, int k, const float* x, int64_t sb, int64_t sc, int64_t sw, const float* w,
-                         const float* bias, float* col, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
-  if (!x || !w || !col || !y || B < 1 || Cin < 1 || Cout < 1 || k < 1 || W < k) return MVAE_ERR_INVALID;
-  if (((long)Cin * k) % 4) return MVAE_ERR_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  const int Wout = W - k + 1;
-  const long K = (long)Cin * k;
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((long)B * Wout * K, 256, 8192)), dim3(256), 0, st, B, Cin, W, k, x, sb, sc, sw, col);
-  MVAE_CHECK_HIP(hipGetLastError());
-  return launch_gemm_nt(MVAE_F32, B * Wout, Cout, (int)K, col, K, w, K, y, ldy, MVAE_F32, bias, MVAE_ACT_SELU, 0, ws, ws_bytes, st);
-}
-
-static inline long pad4(long x) { return (x + 3) & ~3L; }
-size_t mvae_conv1d_selu_bwd_workspace(int B, int Cin, int W, int Cout, int k) {
-  const long Wout = W - k + 1, M = (long)B * Wout, K = (long)Cin * k, Mp = pad4(M);
-  size_t dcol = (size_t)M * K * 4, dyT = (size_t)Cout * Mp * 4, colT = (size_t)K * Mp * 4;
-  size_t g = gemm_nt_workspace_bytes(Cout, (int)K, (int)Mp, MVAE_F32);
-  size_t g2 = gemm_nt_workspace_bytes((int)M, (int)K, Cout, MVAE_F32);
-  size_t g3 = colsum_workspace_bytes((int)M, Cout);
-  if (g2 > g) g = g2;
-  if (g3 > g) g = g3;
-  return dcol + dyT + colT + g + 256;
-}
-int mvae_conv1d_selu_bwd(int B, int Cin, int W, int Cout, int k, float* dy, int64_t lddy, const float* y, int64_t ldy, const float* col,
-                         const float* wT, int64_t ldwT, float* dw, float* db, float* dx, int64_t dx_sb, int64_t dx_sc, int64_t dx_sw,
-                         void* ws, size_t ws_bytes, void* stream) {
-  if (!dy || !y || !col || !wT || !dw || !db || !ws) return MVAE_ERR_INVALID;
-  if (lddy != ldy || lddy != Cout || (Cout & 3) || ldwT < Cout) return MVAE_ERR_INVALID;   // contiguous [M, Cout], Cout % 4 == 0
-  if (ws_bytes < mvae_conv1d_selu_bwd_workspace(B, Cin, W, Cout, k)) return MVAE_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  const long Wout = W - k + 1, M = (long)B * Wout, K = (long)Cin * k, Mp = pad4(M);
-  char* wp = reinterpret_cast<char*>(ws);
-  float* dcol = reinterpret_cast<float*>(wp); wp += (size_t)M * K * 4;
-  float* dyT = reinterpret_cast<float*>(wp); wp += (size_t)Cout * Mp * 4;
-  float* colT = reinterpret_cast<float*>(wp); wp += (size_t)K * Mp * 4;
-  void* gws = wp; size_t gws_bytes = ws_bytes - (size_t)(wp - reinterpret_cast<char*>(ws));
-  int rc;
-  if ((rc = launch_selu_bwd(M * Cout, dy, y, st))) return rc;                                  // dy <- dpre
-  if ((rc = launch_colsum((int)M, Cout, dy, Cout, db, gws, gws_bytes, st))) return rc;
-  if ((rc = launch_cast_transpose(MVAE_F32, MVAE_F32, (int)M, Cout, dy, Cout, nullptr, 0, dyT, Mp, st))) return rc;
-  if ((rc = launch_cast_transpose(MVAE_F32, MVAE_F32, (int)M, (int)K, col, K, nullptr, 0, colT, Mp, st))) return rc;
-  // dw[Cout, K] = dpre^T . col
-  if ((rc = launch_gemm_nt(MVAE_F32, Cout, (int)K, (int)Mp, dyT, Mp, colT, Mp, dw, K, MVAE_F32, nullptr, 0, 0, gws, gws_bytes, st))) return rc;
-  if (dx) {
-    // dcol[M, K] = dpre[M, Cout] . w[Cout, K]  (B operand = w^T [K, ldwT])
-    if ((rc = launch_gemm_nt(MVAE_F32, (int)M, (int)K, Cout, dy, Cout, wT, ldwT, dcol, K, MVAE_F32, nullptr, 0, 0, gws, gws_bytes, st))) return rc;
-    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)B * Cin * W, 256, 8192)), dim3(256), 0, st, B, Cin, W, k, dcol, dx, dx_sb, dx_sc, dx_sw);
-    MVAE_CHECK_HIP(hipGetLastError());
-  }
-  return MVAE_OK;
 }
 
 int mvae_lambda_fwd(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar, void* stream) {

@@ -13,7 +13,15 @@ struct GemmArgs {
   int c_dtype, act, accumulate;
   int tiles_m, tiles_n, splits;
   long kper;   // K elements per split (multiple of the K-step)
+  // Row groups ("sliding windows"): when group > 0, operand row r starts at element (r / group) * gstride + (r % group) * ld
+  // instead of r * ld -- rows of one group may OVERLAP (ld smaller than the row length), which is how a channels-last Conv1d
+  // reads its im2col matrix straight out of the activation tensor.  a_total / b_total: elements in the operand buffer (bounds).
+  int a_group, b_group;
+  long a_gstride, b_gstride, a_total, b_total;
 };
+__device__ __forceinline__ long grow(int r, int group, long gstride, long ld) {
+  return group > 0 ? (long)(r / group) * gstride + (long)(r % group) * ld : (long)r * ld;
+}
 
 __device__ __forceinline__ void store_out(void* C, long off, int c_dtype, float v, int accumulate) {
   if (c_dtype == MVAE_F32) {
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 
   const T* A = reinterpret_cast<const T*>(p.A);
   const T* B = reinterpret_cast<const T*>(p.B);
-  auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < p.M ? A + (long)gm * p.lda : nullptr; };
+  auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < p.M ? A + grow(gm, p.a_group, p.a_gstride, p.lda) : nullptr; };
   auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < p.N ? B + (long)gn * p.ldb : nullptr; };
 
   f32x4 acc[MI][NI];
@@ -62,9 +70,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     constexpr int NBUF = 4;
     PipeSeg<BM, BN> s0, s1;
     const uint32_t sz = (uint32_t)sizeof(T);
-    auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < p.M ? (uint32_t)gm * (uint32_t)p.lda * sz : PIPE_OOB; };
+    auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < p.M ? (uint32_t)grow(gm, p.a_group, p.a_gstride, p.lda) * sz : PIPE_OOB; };
     auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < p.N ? (uint32_t)gn * (uint32_t)p.ldb * sz : PIPE_OOB; };
-    const uint32_t bytesA = (uint32_t)((long)p.M * p.lda * sz - kbeg * sz), bytesB = (uint32_t)((long)p.N * p.ldb * sz - kbeg * sz);
+    const uint32_t bytesA = (uint32_t)(p.a_total * sz - kbeg * sz), bytesB = (uint32_t)((long)p.N * p.ldb * sz - kbeg * sz);
     pipe_seg_init<T, BM, BN>(s0, A + kbeg, bytesA, B + kbeg, bytesB, offA, offB, (int)(kend - kbeg), tid);
     s1 = s0; s1.nk = 0;
     tile_gemm_pipe<T, BM, BN, MI, NI, NBUF, NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
@@ -193,6 +201,12 @@ size_t gemm_nt_workspace_bytes(int M, int N, int K, int dtype) {
 
 int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                    int c_dtype, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  return launch_gemm_nt_grouped(dtype, M, N, K, A, lda, 0, 0, (long)M * lda, B, ldb, C, ldc, c_dtype, bias, act, accumulate, ws, ws_bytes, st);
+}
+
+int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long lda, int a_group, long a_gstride, long a_total,
+                           const void* B, long ldb, void* C, long ldc, int c_dtype, const float* bias, int act, int accumulate,
+                           void* ws, size_t ws_bytes, hipStream_t st) {
   if (M <= 0 || N <= 0) return MVAE_OK;
   if (K < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
   if (dtype != MVAE_F32 && dtype != MVAE_BF16) return MVAE_ERR_INVALID;
@@ -204,6 +218,7 @@ int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, cons
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
+  p.a_group = a_group; p.a_gstride = a_gstride; p.a_total = a_total; p.b_group = 0; p.b_gstride = 0; p.b_total = (long)N * ldb;
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
@@ -214,7 +229,8 @@ int launch_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, cons
   // deep-pipelined LDS-direct path: whole K-steps only, 16-byte aligned rows, operands < 2 GiB
   const bool pipe = (K % ke == 0) && (pl.kper % ke == 0) && (lda % (16 / sz) == 0) && (ldb % (16 / sz) == 0) &&
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0) &&
-                    ((long)M * lda * sz < (1L << 31)) && ((long)N * ldb * sz < (1L << 31)) && K >= 4 * ke;
+                    (a_total * sz < (1L << 31)) && ((long)N * ldb * sz < (1L << 31)) && K >= 4 * ke &&
+                    (a_group == 0 || a_gstride % (16 / sz) == 0);
   const size_t lds = (size_t)(pipe ? 4 : 2) * (pl.bm + pl.bm) * KB;
 #define MVAE_GEMM_LAUNCH(TT_, BM_, PIPE_)                                                             \
   do {                                                                                                \
@@ -289,6 +305,7 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
+  p.a_group = 0; p.b_group = 0; p.a_gstride = 0; p.b_gstride = 0; p.a_total = (long)K * lda; p.b_total = (long)K * ldb;
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
@@ -321,6 +338,166 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
     if (pl.bm == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 8, false>), grid, dim3(256), 3 * (32768 + 16384), st, p);   // 144 KiB ring
     else hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 4, false>), grid, dim3(256), 4 * 32768, st, p);
   }
+  MVAE_CHECK_HIP(hipGetLastError());
+  if (pl.splits > 1) {
+    long n = (long)M * N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    MVAE_CHECK_HIP(hipGetLastError());
+  }
+  return MVAE_OK;
+}
+
+
+// =====================================================================================================================
+// TN GEMM, f32 (exact, v_mfma_f32_16x16x4_f32):  C[M,N] = sum_r A[r][m] * B[r][n], both operands R-major (row = r), optionally
+// with row groups (GemmArgs).  This is the Conv1d weight gradient dW = dz^T . windows(x): the reduction runs over the
+// B * Wout output positions, A rows are dz[b, w, :], B rows are the overlapping windows x[b, w : w + k, :] -- neither the
+// im2col matrix nor a transpose of it is ever materialised.
+// 64 x 64 tile per 256-thread workgroup (4 waves, 2 x 2, wave tile 32 x 32), 32 r-rows per stage, register-staged double
+// buffer.  LDS image [r][64 + 16] floats: the MFMA fragment of lane l is element [r0 + (l >> 4)][m0 + (l & 15)], one
+// ds_read_b32; the +16 pad puts the four r-rows of a wave read on disjoint banks.  Split over r with fp32 slabs.
+// =====================================================================================================================
+constexpr int TNF_BM = 64, TNF_KS = 32, TNF_LD = 80;
+
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
+  __shared__ float As[2][TNF_KS * TNF_LD];
+  __shared__ float Bs[2][TNF_KS * TNF_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * TNF_BM, n0 = tn * TNF_BM;
+  const int split = blockIdx.y;
+  const long rbeg = (long)split * p.kper;
+  const long rend = (rbeg + p.kper < (long)p.K) ? (rbeg + p.kper) : (long)p.K;
+  const float* A = reinterpret_cast<const float*>(p.A);
+  const float* B = reinterpret_cast<const float*>(p.B);
+  // each thread stages 2 float4 of A and 2 of B per stage: r-row = id >> 4, column chunk = id & 15 (id = tid, tid + 256)
+  const int c4 = (tid & 15) * 4;
+  const bool a_vec = (m0 + c4 + 3 < p.M), b_vec = (n0 + c4 + 3 < p.N);     // whole chunk inside the matrix (host checked alignment)
+  float4 ra[2], rb[2];
+  auto load_stage = [&](long r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long r = r0 + (tid >> 4) + i * 16;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (r < rend) {
+        const float* pa = A + grow((int)r, p.a_group, p.a_gstride, p.lda) + m0 + c4;
+        const float* pb = B + grow((int)r, p.b_group, p.b_gstride, p.ldb) + n0 + c4;
+        if (a_vec) va = *reinterpret_cast<const float4*>(pa);
+        else { if (m0 + c4 < p.M) va.x = pa[0]; if (m0 + c4 + 1 < p.M) va.y = pa[1]; if (m0 + c4 + 2 < p.M) va.z = pa[2]; }
+        if (b_vec) vb = *reinterpret_cast<const float4*>(pb);
+        else { if (n0 + c4 < p.N) vb.x = pb[0]; if (n0 + c4 + 1 < p.N) vb.y = pb[1]; if (n0 + c4 + 2 < p.N) vb.z = pb[2]; }
+      }
+      ra[i] = va; rb[i] = vb;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 4) + i * 16;
+      *reinterpret_cast<float4*>(&As[buf][r * TNF_LD + c4]) = ra[i];
+      *reinterpret_cast<float4*>(&Bs[buf][r * TNF_LD + c4]) = rb[i];
+    }
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nst = (int)((rend - rbeg + TNF_KS - 1) / TNF_KS);
+  if (nst > 0) {
+    load_stage(rbeg);
+    store_stage(0);
+    __syncthreads();
+    const int fr = lane >> 4, fc = lane & 15;
+    for (int s = 0; s < nst; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < nst) load_stage(rbeg + (long)(s + 1) * TNF_KS);
+      const float* as = &As[cur][fr * TNF_LD + wm * 32 + fc];
+      const float* bs = &Bs[cur][fr * TNF_LD + wn * 32 + fc];
+#pragma unroll
+      for (int k4 = 0; k4 < TNF_KS / 4; ++k4) {
+        const float a0 = as[k4 * 4 * TNF_LD], a1 = as[k4 * 4 * TNF_LD + 16];
+        const float b0 = bs[k4 * 4 * TNF_LD], b1 = bs[k4 * 4 * TNF_LD + 16];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      if (s + 1 < nst) store_stage(cur ^ 1);
+      __syncthreads();
+    }
+  }
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 32 + j * 16 + lr;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + i * 16 + lq * 4 + r;
+        if (row >= p.M) continue;
+        const float v = acc[i][j][r];
+        if (p.splits > 1) p.partial[((long)split * p.M + row) * p.N + col] = v;
+        else store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
+      }
+    }
+}
+
+namespace {
+Plan make_plan_tn_f32(int M, int N, int R) {
+  Plan pl;
+  pl.bm = TNF_BM;
+  pl.tiles_m = (M + TNF_BM - 1) / TNF_BM; pl.tiles_n = (N + TNF_BM - 1) / TNF_BM;
+  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  long steps = (R + TNF_KS - 1) / TNF_KS;
+  if (steps < 1) steps = 1;
+  int splits = 1;
+  if (tiles < 512 && steps >= 16) {           // two or more workgroups per CU: the f32 MFMA stream of one tile is short on parallelism
+    splits = (int)((768 + tiles - 1) / tiles);
+    const long maxs = steps / 8;
+    if (splits > maxs) splits = (int)maxs;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  const long per = (steps + splits - 1) / splits;
+  pl.splits = (int)((steps + per - 1) / per);
+  pl.kper = per * TNF_KS;
+  return pl;
+}
+}  // namespace
+
+size_t gemm_tn_f32_workspace_bytes(int M, int N, int R) {
+  Plan pl = make_plan_tn_f32(M, N, R);
+  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+}
+
+// A: rows of M floats, B: rows of N floats; group == 0 -> plain row-major [R][ld].  Row starts must be 16-byte aligned
+// (ld, gstride multiples of 4, bases 16-byte aligned) -- checked here.
+int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_group, long a_gstride, const float* B, long ldb, int b_group,
+                       long b_gstride, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (M <= 0 || N <= 0) return MVAE_OK;
+  if (R < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
+  if ((lda | ldb | a_gstride | b_gstride) & 3) return MVAE_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return MVAE_ERR_INVALID;
+  Plan pl = make_plan_tn_f32(M, N, R);
+  GemmArgs p;
+  p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.partial = nullptr;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = R;
+  p.c_dtype = MVAE_F32; p.act = MVAE_ACT_NONE; p.accumulate = accumulate;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
+  p.a_group = a_group; p.a_gstride = a_gstride; p.b_group = b_group; p.b_gstride = b_gstride; p.a_total = 0; p.b_total = 0;
+  if (pl.splits > 1) {
+    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
+    p.partial = reinterpret_cast<float*>(ws);
+  }
+  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;

@@ -276,11 +276,13 @@ class MolEncoder(nn.Module):
                     t = ws.get(f"WihT{l}", (H, 4 * H), torch.float32, dev)
                     ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), 4 * H, H, dst=w, dstT=t)
                     P["Wih"].append(w); P["WihT"].append(t)
+            # conv stack, channels-last with channel counts padded to whole K-steps: packed weights for the sliding-window GEMMs
             for n, conv in (("c1", self.conv_1[0]), ("c2", self.conv_2[0]), ("c3", self.conv_3[0])):
-                K = conv.in_channels * conv.kernel_size
-                t = ws.get(n + "_wT", (K, conv.out_channels), torch.float32, dev)
-                ops.cast_transpose(conv.weight.view(conv.out_channels, K), conv.out_channels, K, dstT=t)
-                P[n + "_wT"] = t
+                Ci, Co, k = conv.in_channels, conv.out_channels, conv.kernel_size
+                ldx, ldo = _pad(Ci, 32), _pad(Co, 32)
+                P[n + "_wp"] = ws.get(n + "_wp", (Co, k * ldx), torch.float32, dev)
+                P[n + "_wq"] = ws.get(n + "_wq", (Ci, k * ldo), torch.float32, dev)
+                ops.conv1d_pack_weights(conv.weight, Ci, Co, k, ldx, P[n + "_wp"], ldo, P[n + "_wq"])
             d1 = self.dense_1[0]
             P["W1T"] = ws.get("W1T", (d1.in_features, d1.out_features), torch.float32, dev)
             ops.cast_transpose(d1.weight, d1.out_features, d1.in_features, dstT=P["W1T"])
@@ -331,14 +333,18 @@ class _EncoderFn(torch.autograd.Function):
         c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
         k = c1.kernel_size
         W1, W2, W3 = H - k + 1, H - 2 * k + 2, H - 3 * k + 3
-        col1 = ws.get("col1", (B * W1, Lq * k), f32, dev); y1 = ws.get("y1", (B * W1, c1.out_channels), f32, dev)
-        ops.conv1d_selu_fwd(hs[-1], (Hp, B * Hp, 1), B, Lq, H, c1.out_channels, k, c1.weight, c1.bias, col1, y1)
-        col2 = ws.get("col2", (B * W2, c2.in_channels * k), f32, dev); y2 = ws.get("y2", (B * W2, c2.out_channels), f32, dev)
-        ops.conv1d_selu_fwd(y1, (W1 * c1.out_channels, 1, c1.out_channels), B, c2.in_channels, W1, c2.out_channels, k,
-                            c2.weight, c2.bias, col2, y2)
-        col3 = ws.get("col3", (B * W3, c3.in_channels * k), f32, dev); y3 = ws.get("y3", (B * W3, c3.out_channels), f32, dev)
-        ops.conv1d_selu_fwd(y2, (W2 * c2.out_channels, 1, c2.out_channels), B, c3.in_channels, W2, c3.out_channels, k,
-                            c3.weight, c3.bias, col3, y3)
+        # channels-last activations [b][w][c] with zero pad channels; conv_1 reads the LSTM output as x1[b][w][t] = hs[t][b][w]
+        L1, O1, O2, O3 = _pad(Lq, 32), _pad(c1.out_channels, 32), _pad(c2.out_channels, 32), _pad(c3.out_channels, 32)
+        if O3 != c3.out_channels:
+            raise L.MvaeError("MolEncoder: conv_3 channel count must be a multiple of 32")
+        x1 = ws.get("x1", (B * Hp, L1), f32, dev)
+        ops.cast_transpose(hs[-1], Lq, B * Hp, dstT=x1, lds=B * Hp)
+        y1 = ws.get("y1", (B * W1, O1), f32, dev)
+        ops.conv1d_selu_fwd(x1, B, H, L1, Hp * L1, c1.out_channels, k, P["c1_wp"], c1.bias, y1, O1)
+        y2 = ws.get("y2", (B * W2, O2), f32, dev)
+        ops.conv1d_selu_fwd(y1, B, W1, O1, W1 * O1, c2.out_channels, k, P["c2_wp"], c2.bias, y2, O2)
+        y3 = ws.get("y3", (B * W3, O3), f32, dev)
+        ops.conv1d_selu_fwd(y2, B, W2, O2, W2 * O2, c3.out_channels, k, P["c3_wp"], c3.bias, y3, O3)
         # Flatten is channel-major (models.py:6-10): flat[b, co*W3 + w] = y3[(b*W3 + w), co]
         C3 = c3.out_channels
         flat = ws.get("flat", (B, C3 * W3), f32, dev)
@@ -413,17 +419,20 @@ class _EncoderFn(torch.autograd.Function):
         C3 = c3.out_channels
         dy3 = W("dy3", (B * W3, C3))
         ops.permute021(dflat, dy3, B, C3, W3)
-        y1, y2, y3 = W("y1", (B * W1, c1.out_channels)), W("y2", (B * W2, c2.out_channels)), W("y3", (B * W3, C3))
-        col1, col2, col3 = W("col1", (B * W1, Lq * k)), W("col2", (B * W2, c2.in_channels * k)), W("col3", (B * W3, c3.in_channels * k))
-        dy2 = W("dy2", (B * W2, c2.out_channels)); dy1 = W("dy1", (B * W1, c1.out_channels)); dhs = W("dhs", (Lq, B, H))
-        ops.conv1d_selu_bwd(B, c3.in_channels, W2, C3, k, dy3, y3, col3, P["c3_wT"], C3, grads["conv_3.0.weight"],
-                            grads["conv_3.0.bias"], dy2, (W2 * c2.out_channels, 1, c2.out_channels))
-        ops.conv1d_selu_bwd(B, c2.in_channels, W1, c2.out_channels, k, dy2, y2, col2, P["c2_wT"], c2.out_channels,
-                            grads["conv_2.0.weight"], grads["conv_2.0.bias"], dy1, (W1 * c1.out_channels, 1, c1.out_channels))
-        ops.conv1d_selu_bwd(B, Lq, H, c1.out_channels, k, dy1, y1, col1, P["c1_wT"], c1.out_channels,
-                            grads["conv_1.0.weight"], grads["conv_1.0.bias"], dhs, (H, B * H, 1))
-        # K2 backward (reverse wavefront) + weight gradients
         Hp = P["Hp"]
+        L1, O1, O2 = _pad(Lq, 32), _pad(c1.out_channels, 32), _pad(c2.out_channels, 32)
+        x1, y1, y2, y3 = W("x1", (B * Hp, L1)), W("y1", (B * W1, O1)), W("y2", (B * W2, O2)), W("y3", (B * W3, C3))
+        dy2, dy1, dx1 = W("dy2", (B * W2, O2)), W("dy1", (B * W1, O1)), W("dx1", (B * H, L1))
+        dzp3, dzp2, dzp1 = W("dzp3", (B * (W3 + 2 * k - 2), C3)), W("dzp2", (B * (W2 + 2 * k - 2), O2)), W("dzp1", (B * (W1 + 2 * k - 2), O1))
+        ops.conv1d_selu_bwd(B, W2, c3.in_channels, O2, W2 * O2, C3, C3, k, dy3, y3, y2, P["c3_wq"], dzp3,
+                            grads["conv_3.0.weight"], grads["conv_3.0.bias"], dy2, O2)
+        ops.conv1d_selu_bwd(B, W1, c2.in_channels, O1, W1 * O1, c2.out_channels, O2, k, dy2, y2, y1, P["c2_wq"], dzp2,
+                            grads["conv_2.0.weight"], grads["conv_2.0.bias"], dy1, O1)
+        ops.conv1d_selu_bwd(B, H, Lq, L1, Hp * L1, c1.out_channels, O1, k, dy1, y1, x1, P["c1_wq"], dzp1,
+                            grads["conv_1.0.weight"], grads["conv_1.0.bias"], dx1, L1)
+        dhs = W("dhs", (Lq, B, H))
+        ops.cast_transpose(dx1, B * H, Lq, dstT=dhs.view(Lq, B * H), lds=L1)          # dhs[t][b][w] = dx1[(b, w)][t]
+        # K2 backward (reverse wavefront) + weight gradients
         hs = [W(f"hs{l}", (Lq, B, Hp)) for l in range(NL)]
         cs = [W(f"cs{l}", (Lq, B, H)) for l in range(NL)]
         gates = [W(f"gates{l}", (Lq, B, G4)) for l in range(NL)]

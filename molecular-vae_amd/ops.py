@@ -177,22 +177,26 @@ def selu_bwd(dy, y):
     check(L.load().mvae_selu_bwd(dy.numel(), ptr(dy), ptr(y), stream_ptr()), "mvae_selu_bwd")
 
 
-def conv1d_selu_fwd(x, strides, B, Cin, W, Cout, k, w, bias, col, y):
+def conv1d_pack_weights(w, Cin, Cout, k, ldx, wp, ldo=0, wq=None):
+    """wp[o][j*ldx + c] = w[o][c][j];  wq[c][j*ldo + o] = w[o][c][k-1-j]  (pads zero)."""
+    check(L.load().mvae_conv1d_pack_weights(Cin, Cout, k, ptr(w), ldx, ptr(wp), ldo, ptr(wq), stream_ptr()), "mvae_conv1d_pack_weights")
+
+
+def conv1d_selu_fwd(x, B, W, ldx, x_bs, Cout, k, wp, bias, y, ldy):
+    """Channels-last sliding-window conv: x[b, w, c] at b*x_bs + w*ldx + c (pad channels zero) -> y[(b*Wout + w), o] (ldy)."""
     lib = L.load()
-    need = lib.mvae_conv1d_selu_fwd_workspace(B, Cin, W, Cout, k)
+    need = lib.mvae_conv1d_selu_fwd_workspace(B, W, ldx, Cout, k)
     ws = Scratch.get(need, x.device) if need else None
-    sb, sc, sw = strides
-    check(lib.mvae_conv1d_selu_fwd(B, Cin, W, Cout, k, ptr(x), sb, sc, sw, ptr(w), ptr(bias), ptr(col), ptr(y), Cout,
-                                   ptr(ws), need, stream_ptr()), "mvae_conv1d_selu_fwd")
+    check(lib.mvae_conv1d_selu_fwd(B, W, ldx, x_bs, Cout, k, ptr(x), ptr(wp), ptr(bias), ptr(y), ldy, ptr(ws), need, stream_ptr()),
+          "mvae_conv1d_selu_fwd")
 
 
-def conv1d_selu_bwd(B, Cin, W, Cout, k, dy, y, col, wT, ldwT, dw, db, dx, dx_strides):
+def conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, db, dx, lddx):
     lib = L.load()
-    need = lib.mvae_conv1d_selu_bwd_workspace(B, Cin, W, Cout, k)
+    need = lib.mvae_conv1d_selu_bwd_workspace(B, W, Cin, ldx, Cout, ldo, k)
     ws = Scratch.get(need, dy.device)
-    sb, sc, sw = dx_strides
-    check(lib.mvae_conv1d_selu_bwd(B, Cin, W, Cout, k, ptr(dy), Cout, ptr(y), Cout, ptr(col), ptr(wT), ldwT, ptr(dw), ptr(db),
-                                   ptr(dx), sb, sc, sw, ptr(ws), need, stream_ptr()), "mvae_conv1d_selu_bwd")
+    check(lib.mvae_conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, ptr(dy), ptr(y), ptr(x), ptr(wq), ptr(dzp), ptr(dw), ptr(db),
+                                   ptr(dx), lddx, ptr(ws), need, stream_ptr()), "mvae_conv1d_selu_bwd")
 
 
 def lambda_fwd(mulv, eps, z, mu, logvar, B, o):

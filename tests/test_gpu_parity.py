@@ -167,6 +167,38 @@ def test_lstm_bwd_split_segment_schedule(split, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("case", [
+    (3, 7, 23, 5, 4, 8, 8, 29),        # tiny, nothing aligned to a K-step: generic loops, ragged tiles
+    (9, 24, 40, 20, 18, 32, 32, 44),   # LDS-direct path (k * ldx % 32 == 0), padded channels, batch stride larger than W * ldx
+    (130, 120, 72, 120, 18, 128, 128, 96),   # conv_1 of the model at batch 130
+    (64, 64, 38, 64, 18, 64, 64, 38),  # conv_3
+])
+def test_conv1d_selu_sliding_window_vs_oracle(case):
+    """Channels-last sliding-window Conv1d + SELU (forward, dX, dW, db) against the oracle's im2col formulation."""
+    B, Cin, W, Cout, k, ldx, ldo, Wbuf = case
+    rs = np.random.RandomState(B + Cin + W)
+    x = rs.standard_normal((B, Cin, W)) * 0.5
+    w = rs.standard_normal((Cout, Cin, k)) * (1.0 / np.sqrt(Cin * k)); b = rs.standard_normal(Cout) * 0.1
+    y_ref, cache = O.conv_selu_fwd(x, w, b)                       # [B, Cout, Wout]
+    Wout = W - k + 1
+    dy = rs.standard_normal(y_ref.shape)
+    dx_ref, dw_ref, db_ref = O.conv_selu_bwd(dy, cache)
+    xd = torch.zeros(B, Wbuf, ldx, device=dev); xd[:, :W, :Cin] = t(x.transpose(0, 2, 1))
+    wd, bd = t(w), t(b)
+    wp = torch.full((Cout, k * ldx), 7.0, device=dev); wq = torch.full((Cin, k * ldo), 7.0, device=dev)
+    ops.conv1d_pack_weights(wd, Cin, Cout, k, ldx, wp, ldo, wq)
+    y = torch.zeros(B * Wout, ldo, device=dev)
+    ops.conv1d_selu_fwd(xd, B, W, ldx, Wbuf * ldx, Cout, k, wp, bd, y, ldo)
+    assert rel(y.view(B, Wout, ldo)[:, :, :Cout].cpu().numpy().transpose(0, 2, 1), y_ref) < 1e-5
+    assert float(y[:, Cout:].abs().sum()) == 0
+    dyd = torch.zeros(B * Wout, ldo, device=dev); dyd[:, :Cout] = t(dy.transpose(0, 2, 1).reshape(B * Wout, Cout))
+    dzp = torch.full((B * (Wout + 2 * k - 2), ldo), 3.0, device=dev)
+    dw = torch.empty(Cout, Cin, k, device=dev); db = torch.empty(Cout, device=dev); dx = torch.zeros(B * W, ldx, device=dev)
+    ops.conv1d_selu_bwd(B, W, Cin, ldx, Wbuf * ldx, Cout, ldo, k, dyd, y, xd, wq, dzp, dw, db, dx, ldx)
+    assert rel(dw.cpu().numpy(), dw_ref) < 1e-5 and rel(db.cpu().numpy(), db_ref) < 1e-5      # f32 sums of up to 3e4 terms vs f64
+    assert rel(dx.view(B, W, ldx)[:, :, :Cin].cpu().numpy().transpose(0, 2, 1), dx_ref) < 1e-5
+
+
 def test_small_ops_vs_oracle():
     rs = np.random.RandomState(3)
     B, Lq, C, o = 5, 11, 12, 16
