@@ -157,11 +157,13 @@ typedef struct {
   void* dGh[MVAE_MAX_LAYERS];                                              /* GRU only: W_hh-side gradient rows */
   float* dstate[MVAE_MAX_LAYERS];                                         /* fp32 [2][B][H] ping-pong: LSTM dc, GRU dh carry */
   float* dh0[MVAE_MAX_LAYERS];                                            /* optional out: gradient w.r.t. h0 (GRU decoder_lat path) */
-  void* split_ws; size_t split_ws_bytes;                                  /* optional scratch >= layers*2*B*H*4 bytes: enables the split-segment
-                                                                             schedule (128x128 partial tiles + element-wise second launch) */
+  void* split_ws; size_t split_ws_bytes;                                  /* optional scratch of mvae_rnn_bwd_workspace(d) bytes: enables the split-K
+                                                                             schedules (fp32 partial tiles of dh summed across workgroups) */
 } mvae_rnn_bwd_desc;
 
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream);
+/* bytes of split_ws that let mvae_rnn_bwd pick any of its schedules for this shape (reads layers, T, B, H only). */
+size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d);
 
 /* out[r] = sum_c X[r, c]  (X dtype, fp32 out; one wave per row, fixed order): bias gradients from dGT. */
 int mvae_rowsum(int dtype, int R, int C, const void* X, int64_t ldx, float* out, int accumulate, void* stream);

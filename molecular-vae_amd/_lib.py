@@ -66,6 +66,7 @@ SIGNATURES = {
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
     "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),
+    "mvae_rnn_bwd_workspace": (_sz, [C.POINTER(RnnBwdDesc)]),
     "mvae_rowsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp]),
     "mvae_timesum": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "mvae_colsum_workspace": (_sz, [_i, _i]),

@@ -4,6 +4,7 @@
 
 int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st);
 int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st);
+size_t rnn_bwd_workspace_bytes(const mvae_rnn_bwd_desc* d);
 
 extern "C" {
 
@@ -36,5 +37,6 @@ int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
 
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) { return rnn_fwd_impl(d, (hipStream_t)stream); }
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
+size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d) { return rnn_bwd_workspace_bytes(d); }
 
 }  // extern "C"

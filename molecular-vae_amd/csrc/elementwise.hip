@@ -238,6 +238,35 @@ __global__ __launch_bounds__(256) void timesum_kernel(int T_, long BW, const T* 
   }
 }
 
+// 16-byte version (bf16): one thread per 8 consecutive elements, four time steps in flight
+__global__ __launch_bounds__(256) void timesum_bf16x8_kernel(int T_, long BW, const bf16_t* X, float* out) {
+  const long n8 = BW / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_t* p = X + i * 8;
+    int t = 0;
+    for (; t + 4 <= T_; t += 4) {
+      uint4 u[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const uint4*>(p + (long)(t + k) * BW);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += __builtin_bit_cast(float, w[e] << 16); acc[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u); }
+      }
+    }
+    for (; t < T_; ++t) {
+      const uint4 u = *reinterpret_cast<const uint4*>(p + (long)t * BW);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += __builtin_bit_cast(float, w[e] << 16); acc[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u); }
+    }
+    *reinterpret_cast<float4*>(out + i * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- Lambda (models.py:80-94)
 __global__ __launch_bounds__(256) void lambda_fwd_kernel(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar) {
   const long n = (long)B * o;
@@ -556,8 +585,11 @@ int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void
   hipStream_t st = (hipStream_t)stream;
   const long BW = (long)B * W;
   if (dtype == MVAE_F32) hipLaunchKernelGGL((timesum_kernel<float>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const float*)X, out);
-  else if (dtype == MVAE_BF16) hipLaunchKernelGGL((timesum_kernel<bf16_t>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
-  else return MVAE_ERR_INVALID;
+  else if (dtype == MVAE_BF16) {
+    if (BW % 8 == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+      hipLaunchKernelGGL(timesum_bf16x8_kernel, dim3(grid_for(BW / 8, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
+    else hipLaunchKernelGGL((timesum_kernel<bf16_t>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
+  } else return MVAE_ERR_INVALID;
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

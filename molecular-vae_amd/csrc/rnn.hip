@@ -617,6 +617,11 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   return MVAE_OK;
 }
 
+size_t rnn_bwd_workspace_bytes(const mvae_rnn_bwd_desc* d) {
+  if (!d || d->layers < 1 || d->B < 1 || d->H < 1) return 0;
+  return (size_t)d->layers * 2 * d->B * d->H * sizeof(float);      // two fp32 partial dh tiles per cell of a wavefront launch
+}
+
 int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   if (!d) return MVAE_ERR_INVALID;
   if (d->cell != MVAE_CELL_LSTM && d->cell != MVAE_CELL_GRU) return MVAE_ERR_UNSUPPORTED;

@@ -290,7 +290,7 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     _fill(d.dstate, dstate)
     if dh0 is not None:
         _fill(d.dh0, dh0)
-    need = NL * 2 * B * H * 4                       # scratch of the split-segment schedule (used only when the shape qualifies)
+    need = L.load().mvae_rnn_bwd_workspace(C.byref(d))     # scratch of the split-K schedules (used only when the shape qualifies)
     sws = Scratch.get(need, dy.device if dy is not None else dG[0].device, tag="rnn_split")
     d.split_ws, d.split_ws_bytes = sws.data_ptr(), need
     with _Timed(tag):
