@@ -6,12 +6,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
-for f in gemm rnn elementwise conv capi; do
+for f in gemm rnn rnn_rowres elementwise conv capi; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hpp -nt build/$f.o ] || [ tile.hpp -nt build/$f.o ] || [ tile_pipe.hpp -nt build/$f.o ] || [ kernels.hpp -nt build/$f.o ] || [ ../../include/mvae.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmvae_hip.so build/gemm.o build/rnn.o build/elementwise.o build/conv.o build/capi.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmvae_hip.so build/gemm.o build/rnn.o build/rnn_rowres.o build/elementwise.o build/conv.o build/capi.o
 echo "built $(cd .. && pwd)/libmvae_hip.so"

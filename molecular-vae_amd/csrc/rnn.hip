@@ -508,6 +508,8 @@ static inline const char* adv(const void* p, long elems, int dtype) {
 }
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st);
+
 int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (!d) return MVAE_ERR_INVALID;
   if (d->cell != MVAE_CELL_LSTM && d->cell != MVAE_CELL_GRU) return MVAE_ERR_UNSUPPORTED;
@@ -526,6 +528,11 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (d->x0 && (!d->w_ih[0] || d->in0 < 1)) return MVAE_ERR_INVALID;
   if (!d->x0 && !d->add0) return MVAE_ERR_INVALID;
   if (d->ldh % epc) return MVAE_ERR_INVALID;
+  // narrow f32 stacks (the encoder): row-resident schedule, one launch per layer instead of one per wavefront step
+  if (tune_int("MVAE_ROWRES", 1)) {
+    const int rc = rnn_rowres_fwd(d, st);
+    if (rc != MVAE_ERR_UNSUPPORTED) return rc;
+  }
   // row tile: the largest of 128 / 64 / 32 that still gives >= 256 workgroups per launch (the f32 MFMA rate is 1/16 of bf16, so
   // f32 stacks prefer many small tiles); MVAE_BM overrides
   auto nblk = [&](int bm) { return (long)((B + bm - 1) / bm) * ((H + 31) / 32) * NL; };
@@ -617,9 +624,14 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   return MVAE_OK;
 }
 
+int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st);
+size_t rnn_rowres_bwd_workspace(int layers, int T, int B, int H);
+
 size_t rnn_bwd_workspace_bytes(const mvae_rnn_bwd_desc* d) {
-  if (!d || d->layers < 1 || d->B < 1 || d->H < 1) return 0;
-  return (size_t)d->layers * 2 * d->B * d->H * sizeof(float);      // two fp32 partial dh tiles per cell of a wavefront launch
+  if (!d || d->layers < 1 || d->B < 1 || d->H < 1 || d->T < 1) return 0;
+  const size_t split = (size_t)d->layers * 2 * d->B * d->H * sizeof(float);      // two fp32 partial dh tiles per cell of a wavefront launch
+  const size_t rowres = rnn_rowres_bwd_workspace(d->layers, d->T, d->B, d->H);   // inter-layer input gradients of the row-resident schedule
+  return split > rowres ? split : rowres;
 }
 
 int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
@@ -640,6 +652,10 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   }
   const long ldg = d->ldg;
   if (ldg < 4L * H || ldg % epc) return MVAE_ERR_INVALID;
+  if (tune_int("MVAE_ROWRES", 1)) {
+    const int rc = rnn_rowres_bwd(d, st);
+    if (rc != MVAE_ERR_UNSUPPORTED) return rc;
+  }
   // bf16: 64-row tiles (two workgroups per CU: one's epilogue runs under the other's main loop); f32: 32 x 32 tiles when the
   // stack is small (MFMA-f32 bound per workgroup).  MVAE_BM overrides.
   int BM = 64, BN = 64;

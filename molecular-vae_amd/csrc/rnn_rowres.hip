@@ -1,0 +1,335 @@
+// Row-resident LSTM schedule for narrow f32 stacks (the reference's encoder: LSTM(30 -> 72, 3 layers), models.py:117,128).
+//
+// The layer-wavefront schedule (rnn.hip) pays one kernel launch per wavefront step; for H = 72 a step is ~0.1 GFLOP, so the
+// 122 dependent launches of a pass are pure launch + cold-cache latency (12 us each, GPU idle).  An LSTM's recurrence only
+// couples the hidden units of ONE batch row, so here a workgroup owns 4 batch rows of one layer and walks the whole time axis
+// by itself: no inter-workgroup communication, one launch per layer (3 per pass), 128 workgroups at B = 512.
+//   * weights live in REGISTERS for the whole pass: wave w holds the K-slice [K/4 * w, K/4 * (w+1)) of [W_ih | W_hh] as the B
+//     operands of v_mfma_f32_4x4x1_16B_f32 (one VGPR per (k, 64 gate columns));
+//   * that MFMA with cbsz = 4 broadcasts the 4-row A block `abid` to all 16 column blocks, i.e. it is a 4 x 64 x 1 outer
+//     product: one VGPR (lane 4b + i <- A[row i][k0 + b]) feeds 16 consecutive k;
+//   * per step: MFMA phase (each wave: its K-slice, all 4H columns) -> partial sums to LDS -> barrier -> gate phase (thread
+//     per (row, unit): sum 4 partials, non-linearities, c/h update in registers, h into the next step's A buffer) -> barrier.
+// Exact f32 (v_mfma_f32_4x4x1 == fmaf chain).  Backward: the same structure over dG . [W_ih | W_hh] (rnn_rowres_bwd).
+#include "common.hpp"
+#include "kernels.hpp"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int RR_ROWS = 4;
+
+template <int KK, int KW, int NG> struct RowMma {
+  static __device__ __forceinline__ void run(const float (&areg)[(KW + 15) / 16], const float (&W)[NG][KW], f32x4 (&C)[NG]) {
+    const float a = areg[KK / 16];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) C[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, W[g][KK], C[g], 4, KK % 16, 0);
+    RowMma<KK + 1, KW, NG>::run(areg, W, C);
+  }
+};
+template <int KW, int NG> struct RowMma<KW, KW, NG> {
+  static __device__ __forceinline__ void run(const float (&)[(KW + 15) / 16], const float (&)[NG][KW], f32x4 (&)[NG]) {}
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct RowResF {
+  const float* x; long ldx;          // layer input [T][B][ldx] (nullptr: layer 0, pre-activations come from `add`)
+  const float* add; long add_ts;     // [T][B][4H] fp32 pre-activation addend, row stride 4H, time stride add_ts (or nullptr)
+  const float* w_ih; long ldw_ih;    // [4H][ldw_ih]
+  const float* w_hh; long ldw_hh;    // [4H][ldw_hh]
+  const float* bias;                 // [4H] or nullptr
+  float* hs; long ldh;               // [T][B][ldh]
+  float* cs;                         // [T][B][H]
+  float* gates;                      // [T][B][4H] post-activation i, f, g, o
+  int T, B;
+};
+
+template <int H, bool HASX>
+__global__ __launch_bounds__(256) void lstm_rowres_fwd_kernel(RowResF p) {
+  constexpr int G4 = 4 * H, K = (HASX ? 2 * H : H), KW = K / 4, NG = (G4 + 63) / 64, NA = (KW + 15) / 16;
+  constexpr int KPAD = 2 * H + 8, NPAD = NG * 64;
+  static_assert(K % 4 == 0 && (KPAD % 32) == 24, "K-slices per wave; A-buffer rows on disjoint banks");
+  __shared__ float abuf[2][RR_ROWS][KPAD];            // [x_t | h_{t-1}] of the 4 rows, double-buffered
+  __shared__ float red[4][RR_ROWS][NPAD];             // per-wave partial pre-activations
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * RR_ROWS, B = p.B, T = p.T;
+
+  // ---- weights -> registers (once): W[g][kk] = Wcat[n = 64 g + lane][k = KW * wave + kk]
+  float W[NG][KW];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int n = 64 * g + lane;
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      const int k = KW * wave + kk;
+      float v = 0.f;
+      if (n < G4) {
+        if (HASX && k < H) v = p.w_ih[(long)n * p.ldw_ih + k];
+        else v = p.w_hh[(long)n * p.ldw_hh + (HASX ? k - H : k)];
+      }
+      W[g][kk] = v;
+    }
+  }
+  // ---- per-thread items of the gate phase: (row, unit) = (id / H, id % H), id = tid (+ 256)
+  constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + 255) / 256;
+  float c_prev[NIT], bia[NIT][4], addv[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256, u = id % H;
+    c_prev[it] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { bia[it][g] = (p.bias && id < NITEM) ? p.bias[g * H + u] : 0.f; addv[it][g] = 0.f; }
+  }
+  // A buffer of step 0: x_0 | zeros
+  for (int i = tid; i < 2 * RR_ROWS * KPAD; i += 256) (&abuf[0][0][0])[i] = 0.f;
+  __syncthreads();
+  const int xr = tid / (H / 4), xc = (tid % (H / 4)) * 4;       // x prefetch: thread -> (row, 4 columns), tid < 4 * H / 4
+  const bool xload = HASX && tid < RR_ROWS * (H / 4) && r0 + xr < B;
+  float4 xpre = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (xload) xpre = *reinterpret_cast<const float4*>(p.x + ((long)(r0 + xr)) * p.ldx + xc);
+  if (HASX && tid < RR_ROWS * (H / 4)) *reinterpret_cast<float4*>(&abuf[0][xr][xc]) = xpre;
+  auto load_add = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256, row = id / H, u = id % H;
+      if (id < NITEM && r0 + row < B) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) addv[it][g] = p.add[(long)t * p.add_ts + (long)(r0 + row) * G4 + g * H + u];
+      }
+    }
+  };
+  if (p.add) load_add(0);
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    // prefetch x_{t+1} (the gate phase stores it into the next A buffer)
+    if (xload && t + 1 < T) xpre = *reinterpret_cast<const float4*>(p.x + ((long)(t + 1) * B + r0 + xr) * p.ldx + xc);
+    // ---- MFMA phase
+    float areg[NA];
+#pragma unroll
+    for (int v = 0; v < NA; ++v) {
+      const int kk = 16 * v + (lane >> 2);
+      areg[v] = (kk < KW) ? abuf[cur][lane & 3][KW * wave + kk] : 0.f;
+    }
+    f32x4 C[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) C[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    RowMma<0, KW, NG>::run(areg, W, C);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
+    __syncthreads();
+    // ---- gate phase
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256, row = id / H, u = id % H;
+      if (id >= NITEM) continue;
+      float pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = g * H + u;
+        pre[g] = ((red[0][row][n] + red[1][row][n]) + (red[2][row][n] + red[3][row][n])) + bia[it][g] + addv[it][g];
+      }
+      const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
+      const float c = gf * c_prev[it] + gi * gg;
+      const float h = go * tanhf(c);
+      c_prev[it] = c;
+      abuf[nxt][row][(HASX ? H : 0) + u] = h;
+      if (r0 + row < B) {
+        const long o = (long)t * B + r0 + row;
+        p.hs[o * p.ldh + u] = h;
+        p.cs[o * H + u] = c;
+        float* g4 = p.gates + o * G4 + u;
+        g4[0] = gi; g4[H] = gf; g4[2 * H] = gg; g4[3 * H] = go;
+      }
+    }
+    if (HASX && tid < RR_ROWS * (H / 4)) *reinterpret_cast<float4*>(&abuf[nxt][xr][xc]) = xpre;
+    if (p.add && t + 1 < T) load_add(t + 1);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------- backward
+struct RowResB {
+  const float* dy; long dy_ld;       // gradient w.r.t. this layer's outputs: row (t * B + b) at dy + (t * B + b) * dy_ld
+  const float* gates; const float* cs;
+  const float* w_ihT; long ldw_ihT;  // [H][ldw] = W_ih^T of THIS layer (nullptr: layer 0, no input gradient)
+  const float* w_hhT; long ldw_hhT;  // [H][ldw] = W_hh^T
+  float* dG; long ldg;               // [T][B][ldg] pre-activation gradients (i, f, g, o)
+  float* dx;                         // [T][B][H] gradient w.r.t. the layer input (HASX only)
+  int T, B;
+};
+
+// One step: gate phase (dG_t from dh_t, dc carry) -> barrier -> MFMA phase: [dx_t | dh_rec_{t-1}] = dG_t . [W_ih | W_hh], wave w
+// contracts gate w's 72 columns -> partial sums to LDS -> barrier.  The partials are summed by the NEXT gate phase.
+template <int H, bool HASX>
+__global__ __launch_bounds__(256) void lstm_rowres_bwd_kernel(RowResB p) {
+  constexpr int G4 = 4 * H, KW = H, NOUT = HASX ? 2 * H : H, NG = (NOUT + 63) / 64, NA = (KW + 15) / 16;
+  constexpr int GPAD = G4 + 24, NPAD = NG * 64, RO = HASX ? H : 0;       // RO: column of dh_rec inside the MFMA output
+  static_assert((GPAD % 32) == 24, "A-buffer rows on disjoint banks");
+  __shared__ float gbuf[RR_ROWS][GPAD];               // dG_t of the 4 rows (A operand)
+  __shared__ float red[4][RR_ROWS][NPAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * RR_ROWS, B = p.B, T = p.T;
+  float W[NG][KW];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int n = 64 * g + lane;
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      const int k = KW * wave + kk;
+      float v = 0.f;
+      if (n < NOUT) {
+        if (HASX && n < H) v = p.w_ihT[(long)n * p.ldw_ihT + k];
+        else v = p.w_hhT[(long)(n - RO) * p.ldw_hhT + k];
+      }
+      W[g][kk] = v;
+    }
+  }
+  constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + 255) / 256;
+  float dc_carry[NIT], c_cur[NIT], c_prev[NIT], gt[NIT][4], dyv[NIT];
+  auto prefetch = [&](int t) {       // gates[t], c[t-1], dy[t]
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256, row = id / H, u = id % H;
+      if (id < NITEM && r0 + row < B) {
+        const long o = (long)t * B + r0 + row;
+        const float* g4 = p.gates + o * G4 + u;
+        gt[it][0] = g4[0]; gt[it][1] = g4[H]; gt[it][2] = g4[2 * H]; gt[it][3] = g4[3 * H];
+        c_prev[it] = (t > 0) ? p.cs[(o - B) * H + u] : 0.f;
+        dyv[it] = p.dy[o * p.dy_ld + u];
+      }
+    }
+  };
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256, row = id / H, u = id % H;
+    dc_carry[it] = 0.f; c_prev[it] = 0.f; dyv[it] = 0.f; c_cur[it] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gt[it][g] = 0.f;
+    if (id < NITEM && r0 + row < B) c_cur[it] = p.cs[((long)(T - 1) * B + r0 + row) * H + u];
+  }
+  prefetch(T - 1);
+  for (int t = T - 1; t >= 0; --t) {
+    // ---- gate phase
+    float gi[NIT], gf[NIT], gg[NIT], go[NIT], cp[NIT], cc[NIT], dyt[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { gi[it] = gt[it][0]; gf[it] = gt[it][1]; gg[it] = gt[it][2]; go[it] = gt[it][3]; cp[it] = c_prev[it]; cc[it] = c_cur[it]; dyt[it] = dyv[it]; }
+    if (t > 0) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) c_cur[it] = c_prev[it];      // c_{t-1} is the next step's cell state
+      prefetch(t - 1);                                               // in flight under this step's math and MFMAs
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256, row = id / H, u = id % H;
+      if (id >= NITEM) continue;
+      float dh = dyt[it];
+      if (t < T - 1) {
+        dh += (red[0][row][RO + u] + red[1][row][RO + u]) + (red[2][row][RO + u] + red[3][row][RO + u]);
+        if (HASX && r0 + row < B)
+          p.dx[((long)(t + 1) * B + r0 + row) * H + u] = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
+      }
+      const float tc = tanhf(cc[it]);
+      const float d_o = dh * tc;
+      const float dc = dh * go[it] * (1.f - tc * tc) + dc_carry[it];
+      dc_carry[it] = dc * gf[it];
+      const float di = dc * gg[it] * gi[it] * (1.f - gi[it]);
+      const float df = dc * cp[it] * gf[it] * (1.f - gf[it]);
+      const float dg = dc * gi[it] * (1.f - gg[it] * gg[it]);
+      const float dO = d_o * go[it] * (1.f - go[it]);
+      gbuf[row][u] = di; gbuf[row][H + u] = df; gbuf[row][2 * H + u] = dg; gbuf[row][3 * H + u] = dO;
+      if (r0 + row < B) {
+        float* d4 = p.dG + ((long)t * B + r0 + row) * p.ldg + u;
+        d4[0] = di; d4[H] = df; d4[2 * H] = dg; d4[3 * H] = dO;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA phase: wave w contracts gate w
+    float areg[NA];
+#pragma unroll
+    for (int v = 0; v < NA; ++v) {
+      const int kk = 16 * v + (lane >> 2);
+      areg[v] = (kk < KW) ? gbuf[lane & 3][KW * wave + kk] : 0.f;
+    }
+    f32x4 C[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) C[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    RowMma<0, KW, NG>::run(areg, W, C);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
+    __syncthreads();
+  }
+  if (HASX) {                                                       // input gradient of step 0
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256, row = id / H, u = id % H;
+      if (id < NITEM && r0 + row < B) p.dx[((long)(r0 + row)) * H + u] = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
+    }
+  }
+}
+
+}  // namespace
+
+// layers of one pass, sequentially; returns MVAE_ERR_UNSUPPORTED when the shape is not the one this schedule is built for
+int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
+  constexpr int H = 72;
+  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || d->x0 || !d->add0 || d->lengths) return MVAE_ERR_UNSUPPORTED;
+  for (int l = 0; l < d->layers; ++l)
+    if (d->h0[l]) return MVAE_ERR_UNSUPPORTED;
+  if (d->ldh % 4 || (reinterpret_cast<uintptr_t>(d->hs[0]) & 15)) return MVAE_ERR_UNSUPPORTED;
+  const int T = d->T, B = d->B;
+  for (int l = 0; l < d->layers; ++l) {
+    RowResF a;
+    a.x = l ? reinterpret_cast<const float*>(d->hs[l - 1]) : nullptr; a.ldx = d->ldh;
+    a.add = l ? nullptr : d->add0; a.add_ts = d->add0_tstride;
+    a.w_ih = l ? reinterpret_cast<const float*>(d->w_ih[l]) : nullptr; a.ldw_ih = d->ldw_ih[l];
+    a.w_hh = reinterpret_cast<const float*>(d->w_hh[l]); a.ldw_hh = d->ldw_hh[l];
+    a.bias = d->bias[l];
+    a.hs = reinterpret_cast<float*>(d->hs[l]); a.ldh = d->ldh;
+    a.cs = reinterpret_cast<float*>(d->cs[l]); a.gates = reinterpret_cast<float*>(d->gates[l]);
+    a.T = T; a.B = B;
+    if (l && (reinterpret_cast<uintptr_t>(d->hs[l - 1]) & 15)) return MVAE_ERR_UNSUPPORTED;
+    dim3 grid((B + RR_ROWS - 1) / RR_ROWS), block(256);
+    if (l) hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, false>), grid, block, 0, st, a);
+  }
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+size_t rnn_rowres_bwd_workspace(int layers, int T, int B, int H) { return (H == 72 && layers > 1) ? (size_t)2 * T * B * H * sizeof(float) : 0; }
+
+// top layer first; layer l's input gradient (dx, scratch ping-pong) is layer l-1's dy
+int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
+  constexpr int H = 72;
+  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || !d->dy || d->lengths) return MVAE_ERR_UNSUPPORTED;
+  const int NL = d->layers, T = d->T, B = d->B;
+  for (int l = 0; l < NL; ++l)
+    if (d->dh_last[l] || d->dh0[l] || d->h0[l]) return MVAE_ERR_UNSUPPORTED;
+  const size_t need = rnn_rowres_bwd_workspace(NL, T, B, H);
+  if (need && (!d->split_ws || d->split_ws_bytes < need)) return MVAE_ERR_UNSUPPORTED;
+  float* dxbuf[2] = {reinterpret_cast<float*>(d->split_ws), reinterpret_cast<float*>(d->split_ws) + (size_t)T * B * H};
+  const float* dy = d->dy; long dy_ld = d->dy_ld;
+  for (int l = NL - 1; l >= 0; --l) {
+    RowResB a;
+    a.dy = dy; a.dy_ld = dy_ld;
+    a.gates = reinterpret_cast<const float*>(d->gates[l]); a.cs = reinterpret_cast<const float*>(d->cs[l]);
+    a.w_ihT = l ? reinterpret_cast<const float*>(d->w_ihT[l]) : nullptr; a.ldw_ihT = d->ldw_ihT[l];
+    a.w_hhT = reinterpret_cast<const float*>(d->w_hhT[l]); a.ldw_hhT = d->ldw_hhT[l];
+    a.dG = reinterpret_cast<float*>(d->dG[l]); a.ldg = d->ldg;
+    a.dx = l ? dxbuf[l & 1] : nullptr;
+    a.T = T; a.B = B;
+    dim3 grid((B + RR_ROWS - 1) / RR_ROWS), block(256);
+    if (l) hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, false>), grid, block, 0, st, a);
+    dy = a.dx; dy_ld = H;
+  }
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
