@@ -31,7 +31,14 @@ template <int KW, int NG> struct RowMma<KW, KW, NG> {
   static __device__ __forceinline__ void run(const float (&)[(KW + 15) / 16], const float (&)[NG][KW], f32x4 (&)[NG]) {}
 };
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms: absolute error ~1e-7, far inside the 1e-4 the encoder outputs are held to (tests: 1e-5)
+__device__ __forceinline__ float sigm(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float t = __expf(-2.f * fabsf(x));
+  return copysignf(__fdividef(1.f - t, 1.f + t), x);
+}
+// NTHR = 320: waves 0-3 run the MFMA phase (one K-slice each), all 5 waves share the gate phase (one (row, unit) item per thread).
+// NTHR = 256 where the weight fragments need more than 256 VGPRs per wave (backward with an input gradient: 216 + state).
 
 struct RowResF {
   const float* x; long ldx;          // layer input [T][B][ldx] (nullptr: layer 0, pre-activations come from `add`)
@@ -45,8 +52,8 @@ struct RowResF {
   int T, B;
 };
 
-template <int H, bool HASX>
-__global__ __launch_bounds__(256) void lstm_rowres_fwd_kernel(RowResF p) {
+template <int H, bool HASX, int NTHR>
+__global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
   constexpr int G4 = 4 * H, K = (HASX ? 2 * H : H), KW = K / 4, NG = (G4 + 63) / 64, NA = (KW + 15) / 16;
   constexpr int KPAD = 2 * H + 8, NPAD = NG * 64;
   static_assert(K % 4 == 0 && (KPAD % 32) == 24, "K-slices per wave; A-buffer rows on disjoint banks");
@@ -62,9 +69,9 @@ __global__ __launch_bounds__(256) void lstm_rowres_fwd_kernel(RowResF p) {
     const int n = 64 * g + lane;
 #pragma unroll
     for (int kk = 0; kk < KW; ++kk) {
-      const int k = KW * wave + kk;
+      const int k = KW * (wave & 3) + kk;
       float v = 0.f;
-      if (n < G4) {
+      if (n < G4 && wave < 4) {
         if (HASX && k < H) v = p.w_ih[(long)n * p.ldw_ih + k];
         else v = p.w_hh[(long)n * p.ldw_hh + (HASX ? k - H : k)];
       }
@@ -72,17 +79,17 @@ __global__ __launch_bounds__(256) void lstm_rowres_fwd_kernel(RowResF p) {
     }
   }
   // ---- per-thread items of the gate phase: (row, unit) = (id / H, id % H), id = tid (+ 256)
-  constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + 255) / 256;
+  constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + NTHR - 1) / NTHR;
   float c_prev[NIT], bia[NIT][4], addv[NIT][4];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int id = tid + it * 256, u = id % H;
+    const int id = tid + it * NTHR, u = id % H;
     c_prev[it] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) { bia[it][g] = (p.bias && id < NITEM) ? p.bias[g * H + u] : 0.f; addv[it][g] = 0.f; }
   }
   // A buffer of step 0: x_0 | zeros
-  for (int i = tid; i < 2 * RR_ROWS * KPAD; i += 256) (&abuf[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * RR_ROWS * KPAD; i += NTHR) (&abuf[0][0][0])[i] = 0.f;
   __syncthreads();
   const int xr = tid / (H / 4), xc = (tid % (H / 4)) * 4;       // x prefetch: thread -> (row, 4 columns), tid < 4 * H / 4
   const bool xload = HASX && tid < RR_ROWS * (H / 4) && r0 + xr < B;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_fwd_kernel(RowResF p) {
   auto load_add = [&](int t) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * 256, row = id / H, u = id % H;
+      const int id = tid + it * NTHR, row = id / H, u = id % H;
       if (id < NITEM && r0 + row < B) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) addv[it][g] = p.add[(long)t * p.add_ts + (long)(r0 + row) * G4 + g * H + u];
@@ -107,25 +114,27 @@ __global__ __launch_bounds__(256) void lstm_rowres_fwd_kernel(RowResF p) {
     // prefetch x_{t+1} (the gate phase stores it into the next A buffer)
     if (xload && t + 1 < T) xpre = *reinterpret_cast<const float4*>(p.x + ((long)(t + 1) * B + r0 + xr) * p.ldx + xc);
     // ---- MFMA phase
-    float areg[NA];
+    if (wave < 4) {
+      float areg[NA];
 #pragma unroll
-    for (int v = 0; v < NA; ++v) {
-      const int kk = 16 * v + (lane >> 2);
-      areg[v] = (kk < KW) ? abuf[cur][lane & 3][KW * wave + kk] : 0.f;
+      for (int v = 0; v < NA; ++v) {
+        const int kk = 16 * v + (lane >> 2);
+        areg[v] = (kk < KW) ? abuf[cur][lane & 3][KW * wave + kk] : 0.f;
+      }
+      f32x4 C[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) C[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      RowMma<0, KW, NG>::run(areg, W, C);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     }
-    f32x4 C[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) C[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    RowMma<0, KW, NG>::run(areg, W, C);
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     __syncthreads();
     // ---- gate phase
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * 256, row = id / H, u = id % H;
+      const int id = tid + it * NTHR, row = id / H, u = id % H;
       if (id >= NITEM) continue;
       float pre[4];
 #pragma unroll
@@ -133,9 +142,9 @@ __global__ __launch_bounds__(256) void lstm_rowres_fwd_kernel(RowResF p) {
         const int n = g * H + u;
         pre[g] = ((red[0][row][n] + red[1][row][n]) + (red[2][row][n] + red[3][row][n])) + bia[it][g] + addv[it][g];
       }
-      const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
+      const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanh_fast(pre[2]), go = sigm(pre[3]);
       const float c = gf * c_prev[it] + gi * gg;
-      const float h = go * tanhf(c);
+      const float h = go * tanh_fast(c);
       c_prev[it] = c;
       abuf[nxt][row][(HASX ? H : 0) + u] = h;
       if (r0 + row < B) {
@@ -165,8 +174,8 @@ struct RowResB {
 
 // One step: gate phase (dG_t from dh_t, dc carry) -> barrier -> MFMA phase: [dx_t | dh_rec_{t-1}] = dG_t . [W_ih | W_hh], wave w
 // contracts gate w's 72 columns -> partial sums to LDS -> barrier.  The partials are summed by the NEXT gate phase.
-template <int H, bool HASX>
-__global__ __launch_bounds__(256) void lstm_rowres_bwd_kernel(RowResB p) {
+template <int H, bool HASX, int NTHR>
+__global__ __launch_bounds__(NTHR) void lstm_rowres_bwd_kernel(RowResB p) {
   constexpr int G4 = 4 * H, KW = H, NOUT = HASX ? 2 * H : H, NG = (NOUT + 63) / 64, NA = (KW + 15) / 16;
   constexpr int GPAD = G4 + 24, NPAD = NG * 64, RO = HASX ? H : 0;       // RO: column of dh_rec inside the MFMA output
   static_assert((GPAD % 32) == 24, "A-buffer rows on disjoint banks");
@@ -180,21 +189,21 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_kernel(RowResB p) {
     const int n = 64 * g + lane;
 #pragma unroll
     for (int kk = 0; kk < KW; ++kk) {
-      const int k = KW * wave + kk;
+      const int k = KW * (wave & 3) + kk;
       float v = 0.f;
-      if (n < NOUT) {
+      if (n < NOUT && wave < 4) {
         if (HASX && n < H) v = p.w_ihT[(long)n * p.ldw_ihT + k];
         else v = p.w_hhT[(long)(n - RO) * p.ldw_hhT + k];
       }
       W[g][kk] = v;
     }
   }
-  constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + 255) / 256;
+  constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + NTHR - 1) / NTHR;
   float dc_carry[NIT], c_cur[NIT], c_prev[NIT], gt[NIT][4], dyv[NIT];
   auto prefetch = [&](int t) {       // gates[t], c[t-1], dy[t]
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * 256, row = id / H, u = id % H;
+      const int id = tid + it * NTHR, row = id / H, u = id % H;
       if (id < NITEM && r0 + row < B) {
         const long o = (long)t * B + r0 + row;
         const float* g4 = p.gates + o * G4 + u;
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_kernel(RowResB p) {
   };
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int id = tid + it * 256, row = id / H, u = id % H;
+    const int id = tid + it * NTHR, row = id / H, u = id % H;
     dc_carry[it] = 0.f; c_prev[it] = 0.f; dyv[it] = 0.f; c_cur[it] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) gt[it][g] = 0.f;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_kernel(RowResB p) {
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * 256, row = id / H, u = id % H;
+      const int id = tid + it * NTHR, row = id / H, u = id % H;
       if (id >= NITEM) continue;
       float dh = dyt[it];
       if (t < T - 1) {
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_kernel(RowResB p) {
         if (HASX && r0 + row < B)
           p.dx[((long)(t + 1) * B + r0 + row) * H + u] = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
       }
-      const float tc = tanhf(cc[it]);
+      const float tc = tanh_fast(cc[it]);
       const float d_o = dh * tc;
       const float dc = dh * go[it] * (1.f - tc * tc) + dc_carry[it];
       dc_carry[it] = dc * gf[it];
@@ -249,26 +258,28 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_kernel(RowResB p) {
     }
     __syncthreads();
     // ---- MFMA phase: wave w contracts gate w
-    float areg[NA];
+    if (wave < 4) {
+      float areg[NA];
 #pragma unroll
-    for (int v = 0; v < NA; ++v) {
-      const int kk = 16 * v + (lane >> 2);
-      areg[v] = (kk < KW) ? gbuf[lane & 3][KW * wave + kk] : 0.f;
+      for (int v = 0; v < NA; ++v) {
+        const int kk = 16 * v + (lane >> 2);
+        areg[v] = (kk < KW) ? gbuf[lane & 3][KW * wave + kk] : 0.f;
+      }
+      f32x4 C[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) C[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      RowMma<0, KW, NG>::run(areg, W, C);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     }
-    f32x4 C[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) C[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    RowMma<0, KW, NG>::run(areg, W, C);
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     __syncthreads();
   }
   if (HASX) {                                                       // input gradient of step 0
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * 256, row = id / H, u = id % H;
+      const int id = tid + it * NTHR, row = id / H, u = id % H;
       if (id < NITEM && r0 + row < B) p.dx[((long)(r0 + row)) * H + u] = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
     }
   }
@@ -295,9 +306,9 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     a.cs = reinterpret_cast<float*>(d->cs[l]); a.gates = reinterpret_cast<float*>(d->gates[l]);
     a.T = T; a.B = B;
     if (l && (reinterpret_cast<uintptr_t>(d->hs[l - 1]) & 15)) return MVAE_ERR_UNSUPPORTED;
-    dim3 grid((B + RR_ROWS - 1) / RR_ROWS), block(256);
-    if (l) hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, false>), grid, block, 0, st, a);
+    dim3 grid((B + RR_ROWS - 1) / RR_ROWS);
+    if (l) hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, true, 320>), grid, dim3(320), 0, st, a);
+    else hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, false, 320>), grid, dim3(320), 0, st, a);
   }
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
@@ -325,9 +336,9 @@ int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     a.dG = reinterpret_cast<float*>(d->dG[l]); a.ldg = d->ldg;
     a.dx = l ? dxbuf[l & 1] : nullptr;
     a.T = T; a.B = B;
-    dim3 grid((B + RR_ROWS - 1) / RR_ROWS), block(256);
-    if (l) hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, false>), grid, block, 0, st, a);
+    dim3 grid((B + RR_ROWS - 1) / RR_ROWS);
+    if (l) hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, true, 256>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, false, 320>), grid, dim3(320), 0, st, a);
     dy = a.dx; dy_ld = H;
   }
   MVAE_CHECK_HIP(hipGetLastError());

@@ -13,6 +13,7 @@ rows = c.execute(f"select s.display_name, d.start, d.end, d.queue_id, d.stream_i
 
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*", "", n)
     return n.replace("void ", "")[:90]
 
