@@ -65,8 +65,8 @@ int mvae_gemm_nt(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
 
 /* C[M,N] = act( A^T . B + bias[N] ) with A [K, lda] and B [K, ldb] both K-major (row = k): the weight-gradient contraction
  * dW = dG^T . X reading dG [T*B, 4H] and X [T*B, H] as the recurrent kernels wrote them (hardware-transposed LDS reads, no
- * transposed copies).  bf16 operands only (MVAE_ERR_UNSUPPORTED otherwise: f32 callers use mvae_cast_transpose + mvae_gemm_nt).
- * lda, ldb multiples of 8; rows k >= K are never read.  Replaces autograd's weight-gradient GEMMs of models.py:128,164,157. */
+ * transposed copies).  bf16 operands: lda, ldb multiples of 8.  f32 operands (exact v_mfma_f32_16x16x4_f32 kernel): lda, ldb
+ * multiples of 4, 16-byte aligned bases, fp32 C, no bias / activation.  Rows k >= K are never read.  Replaces autograd's weight-gradient GEMMs of models.py:128,164,157. */
 size_t mvae_gemm_tn_workspace(int M, int N, int K, int dtype_ab);
 int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
                  void* C, int64_t ldc, int dtype_c, const float* bias, int act, int accumulate,

@@ -27,11 +27,17 @@ int mvae_gemm_nt(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
   return launch_gemm_nt(dtype_ab, M, N, K, A, lda, B, ldb, C, ldc, dtype_c, bias, act, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
-size_t mvae_gemm_tn_workspace(int M, int N, int K, int dtype_ab) { return dtype_ab == MVAE_BF16 ? gemm_tn_workspace_bytes(M, N, K) : 0; }
+size_t mvae_gemm_tn_workspace(int M, int N, int K, int dtype_ab) {
+  return dtype_ab == MVAE_BF16 ? gemm_tn_workspace_bytes(M, N, K) : dtype_ab == MVAE_F32 ? gemm_tn_f32_workspace_bytes(M, N, K) : 0;
+}
 
 int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                  int dtype_c, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, void* stream) {
-  if (dtype_ab != MVAE_BF16) return MVAE_ERR_UNSUPPORTED;   // f32 callers transpose explicitly (mvae_cast_transpose) and use mvae_gemm_nt
+  if (dtype_ab == MVAE_F32) {                                // exact-f32 kernel: plain fp32 result, no fused bias / activation
+    if (dtype_c != MVAE_F32 || bias || act != MVAE_ACT_NONE) return MVAE_ERR_UNSUPPORTED;
+    return launch_gemm_tn_f32(M, N, K, (const float*)A, lda, 0, 0, (const float*)B, ldb, 0, 0, (float*)C, ldc, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  }
+  if (dtype_ab != MVAE_BF16) return MVAE_ERR_UNSUPPORTED;
   return launch_gemm_tn_bf16(M, N, K, A, lda, B, ldb, C, ldc, dtype_c, bias, act, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 

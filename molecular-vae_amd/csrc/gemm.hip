@@ -171,8 +171,11 @@ struct Plan { int bm, tiles_m, tiles_n, splits; long kper; };
 Plan make_plan(int M, int N, int K, int dtype) {
   Plan pl;
   const int ke = (dtype == MVAE_BF16) ? 64 : 32;
-  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  pl.bm = (t128 >= 192) ? 128 : 64;
+  // 128 x 128 tiles when they fill the chip AND their last round of workgroups is not mostly empty (288 tiles on 256 CUs = 2 rounds at
+  // 56 %); otherwise 64 x 64 (four times the tiles: finer tail, and the f32 MFMA rate leaves room for the extra operand traffic)
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  auto eff = [](long t) { return (double)t / (double)(((t + 255) / 256) * 256); };
+  pl.bm = (t128 >= 192 && eff(t128) >= 0.8 * eff(t64)) ? 128 : 64;
   pl.tiles_m = (M + pl.bm - 1) / pl.bm;
   pl.tiles_n = (N + pl.bm - 1) / pl.bm;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;

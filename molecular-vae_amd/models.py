@@ -161,7 +161,7 @@ def _params_key(params):
 
 def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh):
     """dW_ih, dW_hh, db of every layer from the saved pre-activation gradients dG [T*B, 4H] and layer outputs hs [T*B, H].
-    bf16: hardware-transposed TN GEMM straight from the K-major buffers; f32: explicit transposes + NT GEMM."""
+    Both dtypes contract straight from the K-major buffers (bf16: hardware-transposed LDS reads; f32: exact-f32 TN kernel)."""
     G4, TB = 4 * H, Lq * B
     f32 = torch.float32
     if dt == torch.bfloat16:
@@ -175,20 +175,15 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
             ops.colsum_t(a, TB, G4, grads[f"{prefix}.bias_ih_l{l}"], ldx=ldg)
             grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
         return
-    ldT = _pad(TB, 8) + 8          # +8: the time-shifted GEMM may over-read one chunk into zero pad
-    hsT_prev = None
-    for l in range(NL):
-        dGT = ws.get("wg_dGT", (G4, ldT), f32, dev)
-        hsT = ws.get(f"wg_hsT{l & 1}", (H, ldT), f32, dev)
-        ops.cast_transpose(dG[l].view(TB, ldg), TB, G4, dstT=dGT, lds=ldg)
-        ops.cast_transpose(hs[l].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
+    for l in range(NL):                       # f32: the exact-f32 TN kernel, same K-major operands
+        a = dG[l].view(TB, ldg)
+        x = hs[l].view(TB, ldh)
         if Lq > 1:
-            ops.gemm_nt(dGT[:, B:], hsT, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldT, ldb=ldT)
+            ops.gemm_tn(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldg, ldb=ldh)
         if l > 0:
-            ops.gemm_nt(dGT, hsT_prev, grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldT, ldb=ldT)
-        ops.rowsum(dGT, G4, TB, grads[f"{prefix}.bias_ih_l{l}"])
+            ops.gemm_tn(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
+        ops.colsum(a, TB, G4, grads[f"{prefix}.bias_ih_l{l}"], ldx=ldg)
         grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
-        hsT_prev = hsT
 
 
 class Lambda(nn.Module):

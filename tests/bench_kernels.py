@@ -27,11 +27,11 @@ WihT = [None] + [rnd(H, ldwT).to(dt) for _ in range(NL - 1)]
 WhhT = [rnd(H, ldwT).to(dt) for _ in range(NL)]
 bias = [None] + [rnd(G4) for _ in range(NL - 1)]
 gx0 = rnd(B, G4)
-hs = [torch.zeros(T, B, ldh, device=dev, dtype=dt) for _ in range(NL)]
+hs = [rnd(T, B, ldh).to(dt) * 10 for _ in range(NL)]      # random, so that MVAE_DBG=1 (epilogue skipped) still multiplies real operands
 cs = [torch.zeros(T, B, H, device=dev, dtype=dt) for _ in range(NL)]
 cstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
-gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
-dG = [torch.zeros(T, B, ldg, device=dev, dtype=dt) for _ in range(NL)]
+gates = [torch.sigmoid(rnd(T, B, G4) * 20).to(dt) for _ in range(NL)]
+dG = [rnd(T, B, ldg).to(dt) for _ in range(NL)]
 dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
 dy = rnd(T * B, H)
 
