@@ -85,12 +85,22 @@ __global__ __launch_bounds__(256) void scatter_rows_tb_stage1(const int64_t* idx
   __syncthreads();
   const long rbeg = (long)blockIdx.x * rpb;
   long rend = rbeg + rpb; if (rend > total) rend = total;
+  // eight rows per round: their ids and values are requested together (one load latency per round), then applied in row order
   for (int c = threadIdx.x; c < wsl; c += 256) {
-    for (long row = rbeg; row < rend; ++row) {
-      const int t = (int)(row / B), b = (int)(row - (long)t * B);
-      long id = idx[(long)b * L + t];
-      id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
-      tab[id * ws_cols + c] += TT<T>::ld(d + row * ldd + c_lo + c);
+    for (long row0 = rbeg; row0 < rend; row0 += 8) {
+      float v[8]; int id[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const long row = row0 + r;
+        if (row < rend) {
+          const int t = (int)(row / B), b = (int)(row - (long)t * B);
+          long q = idx[(long)b * L + t];
+          id[r] = (int)(q < 0 ? 0 : (q >= nrows ? nrows - 1 : q));
+          v[r] = TT<T>::ld(d + row * ldd + c_lo + c);
+        } else { id[r] = 0; v[r] = 0.f; }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) tab[id[r] * ws_cols + c] += v[r];
     }
   }
   __syncthreads();
@@ -546,7 +556,7 @@ int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float
   return MVAE_OK;
 }
 
-static int scatter_parts(int B, int L) { long rows = (long)B * L; long parts = (rows + 255) / 256; if (parts > 256) parts = 256; return (int)parts; }
+static int scatter_parts(int B, int L) { long rows = (long)B * L; long parts = (rows + 63) / 64; if (parts > 1024) parts = 1024; return (int)parts; }
 size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W) { return (size_t)scatter_parts(B, L) * nrows * W * sizeof(float); }
 int mvae_scatter_rows_tb(int dtype, const int64_t* idx, int B, int L, int nrows, const void* d, int64_t ldd, int W, float* dtable,
                          void* ws, size_t ws_bytes, void* stream) {
