@@ -74,15 +74,22 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the multi-rank "
+                                                       "path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if args.backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())      # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
     import molecular_vae_amd as mv
     from molecular_vae_amd import ops
 
@@ -136,7 +143,7 @@ def main():
     fwd_us = 1e3 * tag_ms.get("dec_lstm_fwd", float("nan")) / n_launch
     bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-    # Dominant SINGLE kernel (profiles/r01_v4_kernel_stats.csv): the forward wavefront step.  The backward step is two kernels per launch
+    # Dominant SINGLE kernel (profiles/r01_v7_kernel_stats.csv): the forward wavefront step.  The backward step is two kernels per launch
     # since the split-segment schedule (partial-tile GEMM + element-wise gate-derivative kernel), each smaller than the forward step;
     # its pair time is reported alongside.
     dom = "lstm_step_fwd_kernel"
@@ -147,7 +154,7 @@ def main():
     # the profiler on itself); null when the shape differs from the profiled one
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_kernels_T16_B512.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v7_pmc_kernels_T16_B512.json")))
         if B == 512 and args.dtype == "bf16":
             for k, v in pm.items():
                 if dom.replace("_kernel", "") in k:
