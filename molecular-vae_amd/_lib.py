@@ -153,3 +153,22 @@ def dt_code(dtype):
 # bumped by in-place parameter updates that bypass torch's version counters (FusedAdam) so that the
 # packed (bf16 / transposed) weight shadows are refreshed
 PARAM_EPOCH = [0]
+
+# Gradient sinks: id(parameter) -> (optimizer, flat gradient buffer, offset, numel).  Registered by train.FusedAdam so that the
+# modules' backward passes write parameter gradients straight into the optimiser's flat buffer (no gather copy) and can start the
+# data-parallel all-reduce of a finished range while the rest of backward is still running.
+GRAD_SINKS = {}
+
+
+def grad_sink_range(params):
+    """(owner, flat, lo, hi) when `params` occupy one contiguous, in-order range of one registered flat buffer; else None."""
+    if not params or id(params[0]) not in GRAD_SINKS:
+        return None
+    owner, flat, lo, _ = GRAD_SINKS[id(params[0])]
+    off = lo
+    for q in params:
+        e = GRAD_SINKS.get(id(q))
+        if e is None or e[0] is not owner or e[1] is not flat or e[2] != off:
+            return None
+        off += e[3]
+    return owner, flat, lo, off

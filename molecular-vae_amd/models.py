@@ -155,6 +155,17 @@ def _require_cuda(dev, what):
         raise L.MvaeError(f"{what} runs on the MI355X only (no CPU fallback); move the module and inputs to cuda")
 
 
+def _grad_buffer(params, dev):
+    """Zeroed flat fp32 buffer for the gradients of `params` (in order): the optimiser's own flat gradient range when the
+    parameters are registered with a FusedAdam and no gradient is pending accumulation, else a fresh tensor."""
+    sink = L.grad_sink_range(params) if all(p.grad is None for p in params) else None
+    if sink is not None and sink[1].device == dev:
+        g = sink[1][sink[2]:sink[3]]
+        g.zero_()
+        return g, sink
+    return torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev), None
+
+
 def _params_key(params):
     return (L.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params)
 
@@ -373,8 +384,7 @@ class _EncoderFn(torch.autograd.Function):
         P = mod._packed
         params = list(mod.parameters())
         names = [n for n, _ in mod.named_parameters()]
-        total = sum(p.numel() for p in params)
-        gflat = torch.zeros(total, dtype=f32, device=dev)
+        gflat, _ = _grad_buffer(params, dev)
         grads, off = {}, 0
         for n, p in zip(names, params):
             grads[n] = gflat[off:off + p.numel()].view(p.shape)
@@ -573,11 +583,11 @@ class _DecoderFn(torch.autograd.Function):
         P = mod._packed
         params = list(mod.parameters())
         names = [n for n, _ in mod.named_parameters()]
-        total = sum(p.numel() for p in params)
-        gflat = torch.zeros(total, dtype=f32, device=dev)
-        grads, off = {}, 0
+        gflat, sink = _grad_buffer(params, dev)
+        grads, off, offs = {}, 0, {}
         for n, p in zip(names, params):
             grads[n] = gflat[off:off + p.numel()].view(p.shape)
+            offs[n] = off
             off += p.numel()
         drecon = drecon.contiguous().float()
         W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
@@ -627,6 +637,11 @@ class _DecoderFn(torch.autograd.Function):
             gflat.record_stream(side)
             with torch.cuda.stream(side):
                 weight_grads()
+                if sink is not None and getattr(sink[0], "grad_sync", None) is not None:
+                    # everything from gru.weight_hh_l0 to the end of our range is final on this stream: all-reduce it now, under the
+                    # encoder's backward (weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step())
+                    lo = sink[2] + offs["gru.weight_hh_l0"]
+                    sink[0].grad_sync.start_early(sink[1], lo, sink[3])
                 e2 = torch.cuda.Event(); e2.record()
             ops.PENDING.append(e2)
         else:

@@ -33,6 +33,7 @@ class GradSync:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.group = group
         self.handles = []
+        self.early = []          # [(flat, lo, hi)] ranges whose all-reduce was started from inside backward (this step)
 
     @property
     def world(self):
@@ -46,10 +47,31 @@ class GradSync:
             self.handles.append(dist.all_reduce(flat[off:min(n, off + self.bucket_elems)], op=dist.ReduceOp.SUM,
                                                 group=self.group, async_op=True))
 
+    def start_early(self, flat, lo, hi):
+        """Called from a module's backward once flat[lo:hi] is final on the CURRENT stream (the collective is ordered after
+        that stream's work): the all-reduce then runs under the rest of backward.  Every rank issues the same calls in the
+        same order (same model, same code path)."""
+        if self.world == 1:
+            return
+        self.start(flat[lo:hi])
+        self.early.append((flat, lo, hi))
+
+    def start_rest(self, flat):
+        """All-reduce whatever part of `flat` start_early has not covered."""
+        done = sorted((lo, hi) for f, lo, hi in self.early if f is flat)
+        pos = 0
+        for lo, hi in done:
+            if lo > pos:
+                self.start(flat[pos:lo])
+            pos = max(pos, hi)
+        if pos < flat.numel():
+            self.start(flat[pos:])
+
     def wait(self):
         for h in self.handles:
             h.wait()
         self.handles = []
+        self.early = []
 
     def grad_scale(self):
         return 1.0 / self.world
@@ -119,6 +141,10 @@ class FusedAdam(torch.optim.Optimizer):
             nparts = (n + (1 << 16) - 1) >> 16
             self._flat.append(dict(params=ps, p=pflat, m=m, v=v, g=g, partial=torch.zeros(nparts, device=dev),
                                    norm=torch.zeros(1, device=dev), step=0))
+            off = 0
+            for p in ps:                 # modules may write their gradients straight into g (see _lib.GRAD_SINKS)
+                L.GRAD_SINKS[id(p)] = (self, g, off, p.numel())
+                off += p.numel()
         L.PARAM_EPOCH[0] += 1
 
     @property
@@ -137,8 +163,8 @@ class FusedAdam(torch.optim.Optimizer):
                 k = p.numel()
                 if p.grad is None:
                     f["g"][off:off + k].zero_()
-                else:
-                    views.append((off, k, p.grad))
+                elif p.grad.data_ptr() != f["g"].data_ptr() + 4 * off or not p.grad.is_contiguous():
+                    views.append((off, k, p.grad))          # (a gradient written in place through the sink needs no copy)
                 off += k
             if views:
                 # one foreach copy: plumbing, not compute
@@ -154,7 +180,7 @@ class FusedAdam(torch.optim.Optimizer):
         sync = self.grad_sync
         if sync is not None:
             for g in flats:
-                sync.start(g)
+                sync.start_rest(g)
             sync.wait()
         scale = sync.grad_scale() if sync is not None else 1.0
         for group, f in zip(self.param_groups, self._flat):

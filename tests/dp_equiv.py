@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Data-parallel equivalence rehearsal on ONE GPU box: K training steps of the full model
+  (a) single process, global batch 2b;   (b) two ranks (gloo, sharing cuda:0), b each, GradSync + early all-reduce
+must give the same losses and parameters (up to fp32 re-association).  Usage on the GPU box:
+  python tests/dp_equiv.py --out gpurun_out/dp1.json
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tests/dp_equiv.py --out gpurun_out/dp2.json
+  python tests/dp_equiv.py --compare gpurun_out/dp1.json gpurun_out/dp2.json"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--out")
+ap.add_argument("--compare", nargs=2)
+ap.add_argument("--b", type=int, default=64)
+ap.add_argument("--steps", type=int, default=4)
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32: re-association noise only (sharp check); bf16: the bench configuration")
+args = ap.parse_args()
+if args.compare:
+    a, b = (json.load(open(f)) for f in args.compare)
+    ok = True
+    for k in ("loss", "psum", "gnorm"):
+        for x, y in zip(a[k], b[k]):
+            rel = abs(x - y) / (abs(x) + 1e-30)
+            print(f"{k}: {x:.8f} vs {y:.8f}  rel {rel:.2e}")
+            ok = ok and rel < 2e-4
+    print("EQUIVALENT" if ok else "MISMATCH")
+    sys.exit(0 if ok else 1)
+
+import molecular_vae_amd as mv
+rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+L_SEQ, VOCAB, LATENT = 120, 35, 292
+torch.manual_seed(42)
+model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
+sync = mv.GradSync() if world > 1 else None
+opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0, grad_sync=sync)
+loss_fn = mv.make_loss_function(L_SEQ)
+g = torch.Generator().manual_seed(7)
+gb = 2 * args.b
+data_all = torch.randint(0, VOCAB, (gb, L_SEQ), generator=g)
+eps_all = 1e-2 * torch.randn(args.steps, gb, LATENT, generator=g)
+per = gb // world
+sl = slice(rank * per, (rank + 1) * per)
+data = data_all[sl].to(dev)
+ohe = torch.nn.functional.one_hot(data, VOCAB).float()
+out = dict(loss=[], psum=[], gnorm=[])
+for s in range(args.steps):
+    eps = eps_all[s, sl].to(dev)
+    opt.zero_grad(set_to_none=True)
+    recon, mu, lv = model(data, eps=eps)
+    loss = loss_fn(recon, ohe, mu, lv)
+    loss.backward()
+    opt.step()
+    lt = loss.detach().clone()
+    if world > 1:
+        dist.all_reduce(lt); lt /= world
+    out["loss"].append(float(lt))
+    out["gnorm"].append(float(opt.last_grad_norm))
+    out["psum"].append(float(sum(p.detach().abs().sum() for p in model.parameters())))
+if rank == 0 and args.out:
+    json.dump(out, open(args.out, "w"))
+    print(out)
+if world > 1:
+    dist.destroy_process_group()
