@@ -29,6 +29,12 @@ def _worker(rank, world, port, out_dir):
     expect = torch.arange(10007, dtype=torch.float32) * sum(r + 1 for r in range(world))
     assert torch.equal(flat, expect)
     assert sync.grad_scale() == 1.0 / world and sync.world == world
+    # 1b) early range (started from inside backward) + the complement in step(): every element reduced exactly once
+    flat = torch.arange(10007, dtype=torch.float32) * (rank + 1)
+    sync.start_early(flat, 3000, 9001)
+    sync.start_early(flat, 100, 200)
+    sync.start_rest(flat); sync.wait()
+    assert torch.equal(flat, expect) and sync.early == [] and sync.handles == []
     # 2) per-shard oracle gradients, all-reduced and scaled, equal the global-batch gradients
     shapes = ip.molvae_shapes(G1["i"], G1["o"], G1["c"], G1["emb"], G1["h_enc"], G1["n_enc"], G1["h_dec"], G1["n_dec"])
     p = ip.init_params(shapes, G1["seed"], G1["gain"], np.float64)
