@@ -146,12 +146,22 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(int M, int N, const 
   const int r0 = blockIdx.y * rows_per_chunk;
   int r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
   float v = 0.f;
-  if (c < N) for (int m = r0 + g; m < r1; m += 4) v += X[(long)m * ldx + c];
+  if (c < N) {
+    // eight independent loads in flight per thread; fixed combination order (deterministic)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int m = r0 + g;
+    for (; m + 28 < r1; m += 32) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += X[(long)(m + 4 * k) * ldx + c];
+    }
+    for (; m < r1; m += 4) a[0] += X[(long)m * ldx + c];
+    v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
   red[g][threadIdx.x & 63] = v;
   __syncthreads();
   if (g == 0 && c < N) partial[(long)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-static int colsum_chunks(int M) { int c = (M + 511) / 512; if (c > 48) c = 48; if (c < 1) c = 1; return c; }
+static int colsum_chunks(int M) { int c = (M + 127) / 128; if (c > 256) c = 256; if (c < 1) c = 1; return c; }
 size_t colsum_workspace_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
 int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
   if (N <= 0) return MVAE_OK;
