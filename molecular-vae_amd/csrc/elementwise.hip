@@ -395,8 +395,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g, floa
   __shared__ float red[4];
   const long beg = (long)blockIdx.x * SUMSQ_CHUNK;
   long end = beg + SUMSQ_CHUNK; if (end > n) end = n;
-  float a = 0.f;
-  for (long i = beg + threadIdx.x; i < end; i += 256) { const float v = g[i]; a += v * v; }
+  // 16-byte loads, four independent accumulators per thread, fixed combination order (deterministic)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const long n4 = (end - beg) / 4;
+  const float4* g4 = reinterpret_cast<const float4*>(g + beg);          // beg is a multiple of 65536 elements: 16-byte aligned
+  long i = threadIdx.x;
+  for (; i + 768 < n4; i += 1024) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float4 v = g4[i + 256 * k]; acc[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+  }
+  for (; i < n4; i += 256) { const float4 v = g4[i]; acc[0] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+  for (long j = beg + 4 * n4 + threadIdx.x; j < end; j += 256) { const float v = g[j]; acc[1] += v * v; }
+  float a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   a = block_sum_256(a, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = a;
 }
@@ -755,7 +765,7 @@ int mvae_bce_kl_loss_bwd(int64_t n, const float* recon, const float* target, int
 
 size_t mvae_sumsq_workspace(int64_t n) { return (size_t)((n + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK) * sizeof(float); }
 int mvae_sumsq(int64_t n, const float* g, float* partial, void* stream) {
-  if (!g || !partial || n < 1) return MVAE_ERR_INVALID;
+  if (!g || !partial || n < 1 || (reinterpret_cast<uintptr_t>(g) & 15)) return MVAE_ERR_INVALID;
   const int blocks = (int)((n + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK);
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)n, g, partial);
   MVAE_CHECK_HIP(hipGetLastError());

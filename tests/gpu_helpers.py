@@ -49,7 +49,7 @@ def run_hip(enc, dec, idx, eps, max_len):
     torch.cuda.synchronize()
     grads = {"encoder." + k: p.grad.detach().cpu().numpy() for k, p in enc.named_parameters()}
     grads.update({"decoder." + k: p.grad.detach().cpu().numpy() for k, p in dec.named_parameters()})
-    return dict(loss=float(loss), z=z.detach().cpu().numpy(), mu=mu.detach().cpu().numpy(),
+    return dict(loss=float(loss.detach()), z=z.detach().cpu().numpy(), mu=mu.detach().cpu().numpy(),
                 logvar=logvar.detach().cpu().numpy(), recon=recon.detach().cpu().numpy(), grads=grads)
 
 

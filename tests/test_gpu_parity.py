@@ -123,6 +123,24 @@ def test_gemm_tn_bf16(shape):
     assert rel(out.cpu().numpy(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 32), (300, 200, 513), (288, 72, 4000), (35, 1024, 1000), (120, 2304, 700), (5, 3, 7)])
+def test_gemm_tn_f32_exact(shape):
+    """C = A^T . B from K-major f32 operands on the exact-f32 MFMA kernel (conv / encoder weight gradients): ragged M/N/K, split over K."""
+    M, N, K = shape
+    rs = np.random.RandomState(M * 3 + N + K)
+    lda, ldb = (M + 3) // 4 * 4 + 4, (N + 3) // 4 * 4 + 8
+    A = torch.zeros(K, lda, device=dev); B = torch.zeros(K, ldb, device=dev)
+    A[:, :M] = t(rs.standard_normal((K, M))); B[:, :N] = t(rs.standard_normal((K, N)))
+    A[:, M:] = 3.0; B[:, N:] = -2.0                      # pads must not leak into the result
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_tn(A, B, out, M, N, K, lda=lda, ldb=ldb)
+    ref = A[:, :M].double().cpu().numpy().T @ B[:, :N].double().cpu().numpy()
+    assert rel(out.cpu().numpy(), ref) < 2e-6
+    acc = out.clone()
+    ops.gemm_tn(A, B, acc, M, N, K, lda=lda, ldb=ldb, accumulate=True)
+    assert rel(acc.cpu().numpy(), 2 * ref) < 2e-6
+
+
 @pytest.mark.parametrize("bm", ["128", "256"])
 @pytest.mark.parametrize("shape", [(300, 200, 513), (4096 + 35, 1024, 200), (256, 128, 64)])
 def test_gemm_tn_bf16_tile_variants(shape, bm, monkeypatch):
