@@ -165,6 +165,49 @@ __global__ __launch_bounds__(WS ? 512 : 256) void gemm_tn_bf16_kernel(GemmArgs p
     }
 }
 
+// 256 x 256 tile, 8 waves (tile_gemm_tn_256): used when it still fills the chip through split-K
+__global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int split = blockIdx.y;
+  const long kbeg = (long)split * p.kper;
+  const long kend = (kbeg + p.kper < (long)p.K) ? (kbeg + p.kper) : (long)p.K;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PipeSegTN2 s;
+  pipe_seg_tn2_init(s, reinterpret_cast<const bf16_t*>(p.A) + kbeg * p.lda, p.lda, m0, reinterpret_cast<const bf16_t*>(p.B) + kbeg * p.ldb, p.ldb, n0,
+                    (int)(kend - kbeg), tid);
+  tile_gemm_tn_256(smem, s, wm, wn, acc, tid);
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + lr;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 128 + i * 16 + lq * 4 + r;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splits > 1) {
+          p.partial[((long)split * p.M + row) * p.N + col] = v;
+        } else {
+          if (p.bias) v += p.bias[col];
+          if (p.act == MVAE_ACT_SELU) v = selu_f(v); else if (p.act == MVAE_ACT_RELU) v = fmaxf(v, 0.f);
+          store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
+        }
+      }
+    }
+}
+
 namespace {
 struct Plan { int bm, tiles_m, tiles_n, splits; long kper; };
 
@@ -269,8 +312,11 @@ Plan make_plan_tn(int M, int N, int K) {
   const char* fe = getenv("MVAE_TN_BM");
   const int force_bm = fe ? atoi(fe) : 0;
   pl.bm = ((long)((M + 255) / 256) * ((N + 127) / 128) >= 128) ? 256 : 128;
-  if (force_bm == 128 || force_bm == 256) pl.bm = force_bm;
-  pl.tiles_m = (M + pl.bm - 1) / pl.bm; pl.tiles_n = (N + 127) / 128;
+  // 256 x 256 (pl.bm = 512 as its tag): another third less operand traffic per FLOP; needs whole tiles' worth of work and enough K to split
+  if ((long)((M + 255) / 256) * ((N + 255) / 256) >= 32 && N % 256 == 0 && K >= 64 * 64) pl.bm = 512;
+  if (force_bm == 128 || force_bm == 256 || force_bm == 512) pl.bm = force_bm;
+  const int bm_rows = pl.bm == 512 ? 256 : pl.bm, bn_cols = pl.bm == 512 ? 256 : 128;
+  pl.tiles_m = (M + bm_rows - 1) / bm_rows; pl.tiles_n = (N + bn_cols - 1) / bn_cols;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   long ksteps = (K + 63) / 64;
   if (ksteps < 1) ksteps = 1;
@@ -321,11 +367,13 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const char* we = getenv("MVAE_TN_WS");
   const bool wspec = we ? atoi(we) != 0 : true;      // loader / consumer wave specialisation (512-thread workgroups)
-  if (wspec) {
+  if (pl.bm == 512) hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, grid, dim3(512), 2 * 65536, st, p);
+  else if (wspec) {
     if (pl.bm == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 8, true>), grid, dim3(512), 3 * (32768 + 16384), st, p);
     else {
       const char* ne = getenv("MVAE_NBUF_TN");

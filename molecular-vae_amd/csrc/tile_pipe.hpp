@@ -448,3 +448,92 @@ __device__ __forceinline__ void tile_gemm_ws(char* smem, const PipeSeg<BM, BN>& 
   }
   ws_barrier();
 }
+
+// =====================================================================================================================
+// TN form, 256 x 256 tile, 512 threads = 8 waves as 2 (m) x 4 (n), wave tile 128 x 64, every wave both loads and computes
+// (two waves per SIMD: one wave's LDS-DMA issue stalls sit under the other's MFMAs).  A 256 x 256 tile needs 64 KB of operands
+// per 64-deep K-step for 8.4 MFLOP -- a third less per FLOP than 256 x 128 -- which is what matters once the loop is bound by
+// the per-CU L2->LDS intake.  Stage = 64 k-rows of A (512-byte rows) + 64 k-rows of B (512-byte rows) = 64 KiB, double-buffered.
+// =====================================================================================================================
+struct PipeSegTN2 {
+  __amdgpu_buffer_rsrc_t ra, rb;
+  uint32_t offA[4], offB[4];
+  uint32_t kstepA, kstepB;
+  int nk;
+};
+
+__device__ __forceinline__ void pipe_seg_tn2_init(PipeSegTN2& s, const void* A, long lda, int m0, const void* B, long ldb, int n0, int K, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  s.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A), 0, (int)((long)K * lda * 2), 0x00020000);
+  s.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(B), 0, (int)((long)K * ldb * 2), 0x00020000);
+  s.nk = (K + 63) / 64;
+  s.kstepA = (uint32_t)(64 * lda * 2);
+  s.kstepB = (uint32_t)(64 * ldb * 2);
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ii = i * 8 + wave;                 // 1-KiB piece = 2 k-rows x 512 bytes
+    const int krow = ii * 2 + (lane >> 5), pc = lane & 31;
+    const uint32_t lc = (uint32_t)((((pc >> 1) ^ tn_f(krow)) << 1) | (pc & 1));
+    s.offA[i] = (uint32_t)krow * (uint32_t)(lda * 2) + (uint32_t)(m0 * 2) + lc * 16u;
+    s.offB[i] = (uint32_t)krow * (uint32_t)(ldb * 2) + (uint32_t)(n0 * 2) + lc * 16u;
+  }
+#endif
+}
+
+__device__ __forceinline__ void pipe_tn2_issue(char* smem, const PipeSegTN2& s, int st, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  char* stage = smem + (st & 1) * 65536;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + (i * 8 + wave) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + (uint32_t)st * s.kstepA, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + 32768 + (i * 8 + wave) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + (uint32_t)st * s.kstepB, 0, 0, 0);
+  }
+#endif
+}
+
+// smem: 2 x 64 KiB.  wm in {0,1}, wn in {0..3}.
+__device__ __forceinline__ void tile_gemm_tn_256(char* smem, const PipeSegTN2& s, int wm, int wn, f32x4 (&acc)[8][4], int tid) {
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = s.nk;
+  if (nk <= 0) return;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const uint32_t f = (uint32_t)(q | ((g & 1) << 2));
+  uint32_t addrA[8], addrB[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) addrA[i] = (uint32_t)(8 * g + q) * 512u + ((((uint32_t)(wm * 8 + i)) ^ f) << 5) + (uint32_t)pp * 8u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) addrB[i] = (uint32_t)(8 * g + q) * 512u + ((((uint32_t)(wn * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u + 32768u;
+  pipe_tn2_issue(smem, s, 0, wave);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();                                         // my pieces of stage kt have landed
+    ws_barrier();                                            // everyone's have; nobody still reads stage kt-1
+    if (kt + 1 < nk) pipe_tn2_issue(smem, s, kt + 1, wave);  // into the buffer stage kt-1 used
+    const uint32_t st = lds0 + (uint32_t)((kt & 1) * 65536);
+    u32x4 a0[8], b0[4], a1[8], b1[4];
+    FragReadTN<0, 8, 512>::template run<0>(a0, addrA, st);
+    FragReadTN<0, 4, 512>::template run<0>(b0, addrB, st);
+    wait_lgkmcnt<0>();
+    FragReadTN<0, 8, 512>::template run<32 * 512>(a1, addrA, st);
+    FragReadTN<0, 4, 512>::template run<32 * 512>(b1, addrB, st);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
+    wait_lgkmcnt<0>();
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        mma16<bf16_t>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
+  }
+  ws_barrier();
+}

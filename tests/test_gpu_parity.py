@@ -141,10 +141,10 @@ def test_gemm_tn_f32_exact(shape):
     assert rel(acc.cpu().numpy(), 2 * ref) < 2e-6
 
 
-@pytest.mark.parametrize("bm", ["128", "256"])
+@pytest.mark.parametrize("bm", ["128", "256", "512"])
 @pytest.mark.parametrize("shape", [(300, 200, 513), (4096 + 35, 1024, 200), (256, 128, 64)])
 def test_gemm_tn_bf16_tile_variants(shape, bm, monkeypatch):
-    """Both TN tiles (128 x 128 and 256 x 128) on ragged shapes, forced through MVAE_TN_BM."""
+    """All TN tiles (128 x 128, 256 x 128, 256 x 256 = tag 512) on ragged shapes, forced through MVAE_TN_BM."""
     monkeypatch.setenv("MVAE_TN_BM", bm)
     test_gemm_tn_bf16(shape)
 
