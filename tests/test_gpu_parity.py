@@ -344,6 +344,44 @@ def test_full_size_properties_batch512():
     assert np.isfinite(float(gn)) and float(gn) > 0
 
 
+def test_long_sequence_config_seq256_vocab64():
+    """BASELINE.json configs[4] shape (seq_len 256, vocab 64) at a modest batch: f32 path against stock torch.nn modules carrying the same
+    weights (oracle/torch_ref.CpuPort), bf16 path against the f32 path, determinism."""
+    from oracle import torch_ref
+    Lq, V, B = 256, 64, 8
+    torch.manual_seed(7)
+    m32 = mv.MolecularVAE(i=Lq, c=V, dtype=torch.float32)
+    ref = torch_ref.CpuPort(i=Lq, o=292, c=V)
+    ref.load_state_dict(m32.state_dict())
+    gen = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, V, (B, Lq), generator=gen)
+    eps = 1e-2 * torch.randn(B, 292, generator=gen)
+    ohe = torch.nn.functional.one_hot(idx, V).float()
+    r_recon, r_mu, r_lv = ref(idx, eps)
+    r_loss = torch_ref.elbo(r_recon, ohe, r_mu, r_lv, Lq)
+    r_loss.backward()
+    m32 = m32.to(dev)
+    recon, mu, lv = m32(idx.to(dev), eps.to(dev))
+    loss = mv.bce_kl_loss(recon, ohe.to(dev), mu, lv, Lq)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(r_loss.detach())) < 1e-5 * abs(float(r_loss.detach()))
+    assert rel(mu.detach().cpu().numpy(), r_mu.detach().numpy()) < 1e-4 and rel(lv.detach().cpu().numpy(), r_lv.detach().numpy()) < 1e-4
+    gr = dict(ref.named_parameters())
+    worst = max(rel(p.grad.cpu().numpy(), gr[n].grad.numpy()) for n, p in m32.named_parameters())
+    assert worst < 2e-4, worst
+    mb = mv.MolecularVAE(i=Lq, c=V).to(dev)                 # bf16 decoder storage
+    mb.load_state_dict(m32.state_dict())
+    out = []
+    for _ in range(2):
+        mb.zero_grad(set_to_none=True)
+        rb, mub, lvb = mb(idx.to(dev), eps.to(dev))
+        lb = mv.bce_kl_loss(rb, ohe.to(dev), mub, lvb, Lq)
+        lb.backward()
+        out.append((float(lb.detach()), float(sum(p.grad.double().abs().sum() for p in mb.parameters()))))
+    assert out[0] == out[1]
+    assert abs(out[0][0] - float(loss.detach())) < 1e-4 * abs(float(loss.detach())) and torch.equal(mub, mu)
+
+
 # ---------------------------------------------------------------------------------------------- MOSES GRU path (mosesvae.py)
 def _moses_setup(golden_dir, dtype):
     from molecular_vae_amd import mosesvae as MV, vocab as VC
