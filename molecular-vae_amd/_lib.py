@@ -65,6 +65,9 @@ SIGNATURES = {
     "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
+    "mvae_gemm_tn_colsum_supported": (_i, [_i, _i, _i]),
+    "mvae_gemm_tn_colsum_workspace": (_sz, [_i, _i, _i]),
+    "mvae_gemm_tn_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
     "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),
     "mvae_rnn_bwd_workspace": (_sz, [C.POINTER(RnnBwdDesc)]),
     "mvae_rowsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp]),

@@ -41,6 +41,15 @@ int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
   return launch_gemm_tn_bf16(M, N, K, A, lda, B, ldb, C, ldc, dtype_c, bias, act, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
+size_t mvae_gemm_tn_colsum_workspace(int M, int N, int K) { return gemm_tn_colsum_supported(M, N, K) ? gemm_tn_colsum_workspace_bytes(M, N, K) : 0; }
+int mvae_gemm_tn_colsum_supported(int M, int N, int K) { return gemm_tn_colsum_supported(M, N, K) ? 1 : 0; }
+int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
+                        float* colsum_out, int colsum_accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (!colsum_out) return MVAE_ERR_INVALID;
+  return launch_gemm_tn_bf16_colsum(M, N, K, A, lda, B, ldb, C, ldc, MVAE_F32, nullptr, MVAE_ACT_NONE, accumulate, colsum_out, colsum_accumulate,
+                                    ws, ws_bytes, (hipStream_t)stream);
+}
+
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) { return rnn_fwd_impl(d, (hipStream_t)stream); }
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d) { return rnn_bwd_workspace_bytes(d); }

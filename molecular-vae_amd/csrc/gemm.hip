@@ -18,6 +18,8 @@ struct GemmArgs {
   // reads its im2col matrix straight out of the activation tensor.  a_total / b_total: elements in the operand buffer (bounds).
   int a_group, b_group;
   long a_gstride, b_gstride, a_total, b_total;
+  // TN 256 x 256 only: column sums of A (out[m] = sum_k A[k][m]) produced alongside C; per-split partials when splits > 1
+  float* colsum_out; float* colsum_partial; int colsum_acc;
 };
 __device__ __forceinline__ long grow(int r, int group, long gstride, long ld) {
   return group > 0 ? (long)(r / group) * gstride + (long)(r % group) * ld : (long)r * ld;
@@ -113,6 +115,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
     if (p.act == MVAE_ACT_SELU) v = selu_f(v); else if (p.act == MVAE_ACT_RELU) v = fmaxf(v, 0.f);
     store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
   }
+  if (p.colsum_out && p.colsum_partial) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.M; i += (long)gridDim.x * 256) {
+      float v = 0.f;
+      for (int s = 0; s < p.splits; ++s) v += p.colsum_partial[(long)s * p.M + i];
+      p.colsum_out[i] = p.colsum_acc ? p.colsum_out[i] + v : v;
+    }
+  }
 }
 
 // C[M,N] = A^T . B with A [K][lda], B [K][ldb] (bf16, K-major): the weight-gradient contraction (see tile_pipe.hpp, TN form).
@@ -166,6 +175,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void gemm_tn_bf16_kernel(GemmArgs p
 }
 
 // 256 x 256 tile, 8 waves (tile_gemm_tn_256): used when it still fills the chip through split-K
+template <bool COLSUM>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
@@ -184,8 +194,23 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(GemmArgs p) {
   PipeSegTN2 s;
   pipe_seg_tn2_init(s, reinterpret_cast<const bf16_t*>(p.A) + kbeg * p.lda, p.lda, m0, reinterpret_cast<const bf16_t*>(p.B) + kbeg * p.ldb, p.ldb, n0,
                     (int)(kend - kbeg), tid);
-  tile_gemm_tn_256(smem, s, wm, wn, acc, tid);
+  f32x4 accb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool colsum = COLSUM && p.colsum_out != nullptr && tn == 0 && wn == 0;       // one column of tiles, one column of waves: wave-uniform
+  tile_gemm_tn_256<COLSUM>(smem, s, wm, wn, acc, colsum, accb, tid);
   const int lr = lane & 15, lq = lane >> 4;
+  if (colsum && lr == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 128 + i * 16 + lq * 4 + r;
+        if (row >= p.M) continue;
+        if (p.splits > 1) p.colsum_partial[(long)split * p.M + row] = accb[i][r];
+        else p.colsum_out[row] = p.colsum_acc ? p.colsum_out[row] + accb[i][r] : accb[i][r];
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -265,6 +290,7 @@ int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long l
   p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
   p.a_group = a_group; p.a_gstride = a_gstride; p.a_total = a_total; p.b_group = 0; p.b_gstride = 0; p.b_total = (long)N * ldb;
+  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = 0;
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
@@ -342,6 +368,19 @@ size_t gemm_tn_workspace_bytes(int M, int N, int K) {
 
 int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
                         const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  return launch_gemm_tn_bf16_colsum(M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, act, accumulate, nullptr, 0, ws, ws_bytes, st);
+}
+
+// colsum_out (optional, fp32 [M]): out[m] (+)= sum_k A[k][m].  Only the 256 x 256 tile produces it: MVAE_ERR_UNSUPPORTED when the plan
+// for this shape is another tile (the caller then uses mvae_colsum_t).
+bool gemm_tn_colsum_supported(int M, int N, int K) { return make_plan_tn(M, N, K).bm == 512; }
+size_t gemm_tn_colsum_workspace_bytes(int M, int N, int K) {
+  Plan pl = make_plan_tn(M, N, K);
+  return pl.splits > 1 ? (size_t)pl.splits * M * (N + 1) * sizeof(float) : 0;
+}
+int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
+                               const float* bias, int act, int accumulate, float* colsum_out, int colsum_acc, void* ws, size_t ws_bytes,
+                               hipStream_t st) {
   if (M <= 0 || N <= 0) return MVAE_OK;
   if (K < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
   if (c_dtype != MVAE_F32 && c_dtype != MVAE_BF16) return MVAE_ERR_INVALID;
@@ -355,11 +394,15 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
   p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
   p.a_group = 0; p.b_group = 0; p.a_gstride = 0; p.b_gstride = 0; p.a_total = (long)K * lda; p.b_total = (long)K * ldb;
+  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = colsum_acc;
+  if (colsum_out && pl.bm != 512) return MVAE_ERR_UNSUPPORTED;
   if (pl.splits > 1) {
-    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    const size_t need = (size_t)pl.splits * M * (N + (colsum_out ? 1 : 0)) * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
     p.partial = reinterpret_cast<float*>(ws);
+    if (colsum_out) p.colsum_partial = p.partial + (size_t)pl.splits * M * N;
   }
+  p.colsum_out = colsum_out;
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits);
   static bool attr_set = false;
   if (!attr_set) {
@@ -367,12 +410,16 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<3, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const char* we = getenv("MVAE_TN_WS");
   const bool wspec = we ? atoi(we) != 0 : true;      // loader / consumer wave specialisation (512-thread workgroups)
-  if (pl.bm == 512) hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, grid, dim3(512), 2 * 65536, st, p);
+  if (pl.bm == 512) {
+    if (colsum_out) hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<true>, grid, dim3(512), 2 * 65536, st, p);
+    else hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<false>, grid, dim3(512), 2 * 65536, st, p);
+  }
   else if (wspec) {
     if (pl.bm == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 8, true>), grid, dim3(512), 3 * (32768 + 16384), st, p);
     else {
@@ -543,6 +590,7 @@ int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_grou
   p.c_dtype = MVAE_F32; p.act = MVAE_ACT_NONE; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
   p.a_group = a_group; p.a_gstride = a_gstride; p.b_group = b_group; p.b_gstride = b_gstride; p.a_total = 0; p.b_total = 0;
+  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = 0;
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;

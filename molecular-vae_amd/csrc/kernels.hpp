@@ -16,6 +16,11 @@ int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_grou
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
 int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
                         const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+bool gemm_tn_colsum_supported(int M, int N, int K);
+size_t gemm_tn_colsum_workspace_bytes(int M, int N, int K);
+int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
+                               const float* bias, int act, int accumulate, float* colsum_out, int colsum_acc, void* ws, size_t ws_bytes,
+                               hipStream_t st);
 int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, long lds_, void* dst, long ldd, void* dstT,
                           long ldt, hipStream_t st);
 size_t colsum_workspace_bytes(int M, int N);

@@ -179,12 +179,22 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
         for l in range(NL):
             a = dG[l].view(TB, ldg)
             x = hs[l].view(TB, ldh)
+            db = grads[f"{prefix}.bias_ih_l{l}"]
+            have_db = False
+            if l > 0:       # bias gradient = column sums of dG: produced by the W_ih GEMM's pass over dG when the fused kernel serves the shape
+                have_db = ops.gemm_tn_colsum(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], db, G4, H, TB, lda=ldg, ldb=ldh)
+                if not have_db:
+                    ops.gemm_tn(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
             if Lq > 1:
-                ops.gemm_tn(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldg, ldb=ldh)
-            if l > 0:
-                ops.gemm_tn(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
-            ops.colsum_t(a, TB, G4, grads[f"{prefix}.bias_ih_l{l}"], ldx=ldg)
-            grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
+                if not have_db and ops.gemm_tn_colsum_supported(a, G4, H, TB - B):
+                    ops.colsum_t(a[:B], B, G4, db, ldx=ldg)                         # the first time step's rows (the shifted GEMM skips them)
+                    ops.gemm_tn_colsum(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], db, G4, H, TB - B, lda=ldg, ldb=ldh, colsum_accumulate=True)
+                    have_db = True
+                else:
+                    ops.gemm_tn(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldg, ldb=ldh)
+            if not have_db:
+                ops.colsum_t(a, TB, G4, db, ldx=ldg)
+            grads[f"{prefix}.bias_hh_l{l}"].copy_(db)
         return
     for l in range(NL):                       # f32: the exact-f32 TN kernel, same K-major operands
         a = dG[l].view(TB, ldg)

@@ -91,6 +91,25 @@ def gemm_tn(A, B, out, M, N, K, lda=None, ldb=None, ldc=None, bias=None, act=L.A
     return out
 
 
+def gemm_tn_colsum_supported(A, M, N, K):
+    return A.dtype == torch.bfloat16 and bool(L.load().mvae_gemm_tn_colsum_supported(M, N, K))
+
+
+def gemm_tn_colsum(A, B, out, colsum_out, M, N, K, lda=None, ldb=None, colsum_accumulate=False):
+    """bf16: out[M,N] = A[:K,:M]^T . B[:K,:N]  and  colsum_out[m] (+)= sum_k A[k,m] from the same pass over A.  Returns False (nothing
+    launched) when the shape is not served by the fused kernel -- the caller then runs gemm_tn + colsum_t."""
+    lib = L.load()
+    if A.dtype != torch.bfloat16 or not lib.mvae_gemm_tn_colsum_supported(M, N, K):
+        return False
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    need = lib.mvae_gemm_tn_colsum_workspace(M, N, K)
+    ws = Scratch.get(need, A.device) if need else None
+    check(lib.mvae_gemm_tn_colsum(M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), out.stride(0), 0, ptr(colsum_out),
+                                  1 if colsum_accumulate else 0, ptr(ws), need, stream_ptr()), "mvae_gemm_tn_colsum")
+    return True
+
+
 def colsum_t(X, M, N, out, ldx=None):
     lib = L.load()
     need = lib.mvae_colsum_t_workspace(M, N)

@@ -123,6 +123,26 @@ def test_gemm_tn_bf16(shape):
     assert rel(out.cpu().numpy(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(4096, 1024, 5000), (2048, 1024, 4096 + 64)])
+def test_gemm_tn_colsum_fused(shape):
+    """Weight gradient and bias gradient from one pass over dG: C = A^T . B and colsum[m] = sum_k A[k][m] (ones-fragment MFMA)."""
+    M, N, K = shape
+    rs = np.random.RandomState(K)
+    lda, ldb = M + 64, N + 64
+    A = torch.zeros(K + 8, lda, device=dev, dtype=torch.bfloat16); B = torch.zeros(K + 8, ldb, device=dev, dtype=torch.bfloat16)
+    A[:K, :M] = t(rs.standard_normal((K, M)), torch.bfloat16); B[:K, :N] = t(rs.standard_normal((K, N)), torch.bfloat16)
+    A[K:] = 5.0                                              # rows beyond K must not be summed
+    assert ops.gemm_tn_colsum_supported(A, M, N, K)
+    out = torch.full((M, N), float("nan"), device=dev); cs = torch.full((M,), float("nan"), device=dev)
+    assert ops.gemm_tn_colsum(A, B, out, cs, M, N, K, lda=lda, ldb=ldb)
+    Ad = A[:K, :M].double().cpu().numpy()
+    ref = Ad.T @ B[:K, :N].double().cpu().numpy()
+    assert rel(out.cpu().numpy(), ref) < 2e-6 and rel(cs.cpu().numpy(), Ad.sum(0)) < 2e-6
+    assert ops.gemm_tn_colsum(A, B, out, cs, M, N, K, lda=lda, ldb=ldb, colsum_accumulate=True)
+    assert rel(cs.cpu().numpy(), 2 * Ad.sum(0)) < 2e-6
+    assert not ops.gemm_tn_colsum_supported(A, 35, 1024, K)  # small shapes: the caller falls back to gemm_tn + colsum_t
+
+
 @pytest.mark.parametrize("shape", [(64, 64, 32), (300, 200, 513), (288, 72, 4000), (35, 1024, 1000), (120, 2304, 700), (5, 3, 7)])
 def test_gemm_tn_f32_exact(shape):
     """C = A^T . B from K-major f32 operands on the exact-f32 MFMA kernel (conv / encoder weight gradients): ragged M/N/K, split over K."""
