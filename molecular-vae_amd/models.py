@@ -14,6 +14,7 @@ Differences that are deliberate and documented:
     The encoder always runs in f32 (mu / logvar parity).
 """
 import math
+import os
 import weakref
 
 import torch
@@ -170,13 +171,14 @@ def _params_key(params):
     return (L.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params)
 
 
-def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh):
+def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=None):
     """dW_ih, dW_hh, db of every layer from the saved pre-activation gradients dG [T*B, 4H] and layer outputs hs [T*B, H].
     Both dtypes contract straight from the K-major buffers (bf16: hardware-transposed LDS reads; f32: exact-f32 TN kernel)."""
     G4, TB = 4 * H, Lq * B
     f32 = torch.float32
+    layers = range(NL) if layers is None else layers
     if dt == torch.bfloat16:
-        for l in range(NL):
+        for l in layers:
             a = dG[l].view(TB, ldg)
             x = hs[l].view(TB, ldh)
             db = grads[f"{prefix}.bias_ih_l{l}"]
@@ -196,7 +198,7 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
                 ops.colsum_t(a, TB, G4, db, ldx=ldg)
             grads[f"{prefix}.bias_hh_l{l}"].copy_(db)
         return
-    for l in range(NL):                       # f32: the exact-f32 TN kernel, same K-major operands
+    for l in layers:                          # f32: the exact-f32 TN kernel, same K-major operands
         a = dG[l].view(TB, ldg)
         x = hs[l].view(TB, ldh)
         if Lq > 1:
@@ -453,6 +455,7 @@ class _EncoderFn(torch.autograd.Function):
         gates = [W(f"gates{l}", (Lq, B, G4)) for l in range(NL)]
         dG = [W(f"dG{l}", (Lq, B, G4)) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
+        ops.run_deferred()        # the decoder's parked weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
         ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, Hp, cs, gates,
                     dG, dstate, tag="enc_lstm_bwd")
         _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp)
@@ -620,24 +623,35 @@ class _DecoderFn(torch.autograd.Function):
         ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [P["ldwT"]] * NL, P["WihT"], [P["ldwT"]] * NL, dy, H, hs, ldh, cs, gates,
                     dG, dstate, ldg=ldg, tag="dec_lstm_bwd")
 
-        def weight_grads():
-            """Everything that only produces parameter gradients (nothing on the path to dz): output head + LSTM weights."""
-            with ops._Timed("dec_lstm_wgrad"):
-                if dt == torch.bfloat16:
-                    ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=Cp, ldb=ldh)
-                    dbp = W("dbout_p", (Cp,))
-                    ops.colsum_t(dl, TB, Cp, dbp, ldx=Cp)
-                    grads["decoded_mean.module.0.bias"].copy_(dbp[:Cv])
-                else:
-                    hsT = W("wg_hsT_out", (H, ldT), dt)
-                    ops.cast_transpose(hs[-1].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
-                    ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
-                    ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
-                _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh)
+        def weight_grads(part):
+            """Everything that only produces parameter gradients (nothing on the path to dz): output head + LSTM weights.
+            part 0: head + the upper layers; part 1: the two lowest layers (parked for the peer, see below); None: everything."""
+            with ops._Timed("dec_lstm_wgrad" if part != 1 else "dec_lstm_wgrad_deferred"):
+                if part != 1:
+                    if dt == torch.bfloat16:
+                        ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=Cp, ldb=ldh)
+                        dbp = W("dbout_p", (Cp,))
+                        ops.colsum_t(dl, TB, Cp, dbp, ldx=Cp)
+                        grads["decoded_mean.module.0.bias"].copy_(dbp[:Cv])
+                    else:
+                        hsT = W("wg_hsT_out", (H, ldT), dt)
+                        ops.cast_transpose(hs[-1].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
+                        ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
+                        ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
+                nlow = min(int(os.environ.get("MVAE_DEFER_LAYERS", "2")), NL - 1)
+                layers = range(NL) if part is None else (range(nlow, NL) if part == 0 else range(nlow))
+                _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers)
+                if part != 0 and sink is not None and getattr(sink[0], "grad_sync", None) is not None:
+                    # everything from gru.weight_hh_l0 to the end of our range is final on this stream: all-reduce it now, under the
+                    # encoder's backward (weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step())
+                    lo = sink[2] + offs["gru.weight_hh_l0"]
+                    sink[0].grad_sync.start_early(sink[1], lo, sink[3])
 
         # Fork: the weight-gradient GEMMs are throughput-bound and independent of dz, while the encoder's backward that follows is a
         # latency-bound chain of small launches -> run them concurrently.  Only when our MolecularVAE peer will join the side stream
         # (its backward ends with ops.join_pending) and no gradient accumulation is pending (p.grad is assigned, never added to).
+        # The two lowest layers' GEMMs are parked (ops.DEFERRED): the peer releases them right before its row-resident LSTM backward,
+        # whose 128 workgroups leave half the CUs idle -- the GEMMs fill them instead of running alone later.
         peer = mod.__dict__["_peer"]() if mod.__dict__["_peer"] is not None else None
         fork = bool(mod.overlap_weight_grads and peer is not None and ctx.needs_input_grad[1] and all(p.grad is None for p in params))
         if fork:
@@ -646,16 +660,12 @@ class _DecoderFn(torch.autograd.Function):
             side.wait_event(e1)
             gflat.record_stream(side)
             with torch.cuda.stream(side):
-                weight_grads()
-                if sink is not None and getattr(sink[0], "grad_sync", None) is not None:
-                    # everything from gru.weight_hh_l0 to the end of our range is final on this stream: all-reduce it now, under the
-                    # encoder's backward (weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step())
-                    lo = sink[2] + offs["gru.weight_hh_l0"]
-                    sink[0].grad_sync.start_early(sink[1], lo, sink[3])
+                weight_grads(0)
                 e2 = torch.cuda.Event(); e2.record()
             ops.PENDING.append(e2)
+            ops.DEFERRED.append((side, lambda: weight_grads(1)))
         else:
-            weight_grads()
+            weight_grads(None)
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
         dgx0 = W("dgx0", (B, ldg))           # pad columns of dG are zero, so the padded time sum is too
         ops.timesum(dG[0], Lq, B, ldg, dgx0)

@@ -40,8 +40,26 @@ class _Timed:
 PENDING = []
 
 
+# (side stream, callable): throughput-bound work its owner parked so that a peer can release it next to a latency-bound phase that leaves
+# most CUs idle (the encoder's row-resident LSTM backward).  Whoever reaches run_deferred() / join_pending() first runs it.
+DEFERRED = []
+
+
+def run_deferred():
+    """Launch every parked piece of work on its side stream, ordered after everything issued so far on the current stream."""
+    while DEFERRED:
+        side, fn = DEFERRED.pop(0)
+        ev = torch.cuda.Event(); ev.record()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
+            e2 = torch.cuda.Event(); e2.record()
+        PENDING.append(e2)
+
+
 def join_pending():
     """Make the current stream wait for every forked piece of work (weight-gradient GEMMs on the side stream)."""
+    run_deferred()
     while PENDING:
         torch.cuda.current_stream().wait_event(PENDING.pop())
 
