@@ -171,16 +171,19 @@ struct RowResB {
   float* dx;                         // [T][B][H] gradient w.r.t. the layer input (HASX only)
   int T, B;
 };
+struct RowResBAll { RowResB l[MVAE_MAX_LAYERS]; int nl; };
 
 // One step: gate phase (dG_t from dh_t, dc carry) -> barrier -> MFMA phase: [dx_t | dh_rec_{t-1}] = dG_t . [W_ih | W_hh], wave w
 // contracts gate w's 72 columns -> partial sums to LDS -> barrier.  The partials are summed by the NEXT gate phase.
-template <int H, bool HASX, int NTHR>
-__global__ __launch_bounds__(NTHR) void lstm_rowres_bwd_kernel(RowResB p) {
-  constexpr int G4 = 4 * H, KW = H, NOUT = HASX ? 2 * H : H, NG = (NOUT + 63) / 64, NA = (KW + 15) / 16;
-  constexpr int GPAD = G4 + 24, NPAD = NG * 64, RO = HASX ? H : 0;       // RO: column of dh_rec inside the MFMA output
-  static_assert((GPAD % 32) == 24, "A-buffer rows on disjoint banks");
-  __shared__ float gbuf[RR_ROWS][GPAD];               // dG_t of the 4 rows (A operand)
-  __shared__ float red[4][RR_ROWS][NPAD];
+// ALL layers of the stack run inside ONE launch, top layer first: layer l's input gradient dx (scratch) is layer l-1's dy, and a
+// workgroup only ever reads the dx rows it wrote itself, so an agent-scope fence + barrier between layers is all the ordering needed.
+// One launch keeps the 128 workgroups resident for the whole pass: they do not have to win their CUs back from concurrently
+// running GEMM workgroups at every layer boundary.  Layer 0 has no input gradient (hasx = false: zero W_ih fragments, no dx stores).
+template <int H, int NTHR>
+__device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, bool HASX, float (&gbuf)[RR_ROWS][4 * H + 24], float (&red)[4][RR_ROWS][192]) {
+  constexpr int G4 = 4 * H, KW = H, NOUT = 2 * H, NG = (NOUT + 63) / 64, NA = (KW + 15) / 16;
+  constexpr int GPAD = G4 + 24, NPAD = NG * 64, RO = H;                  // RO: column of dh_rec inside the MFMA output
+  static_assert((GPAD % 32) == 24 && NPAD == 192, "A-buffer rows on disjoint banks");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * RR_ROWS, B = p.B, T = p.T;
   float W[NG][KW];
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_bwd_kernel(RowResB p) {
       const int k = KW * (wave & 3) + kk;
       float v = 0.f;
       if (n < NOUT && wave < 4) {
-        if (HASX && n < H) v = p.w_ihT[(long)n * p.ldw_ihT + k];
+        if (n < H) v = HASX ? p.w_ihT[(long)n * p.ldw_ihT + k] : 0.f;
         else v = p.w_hhT[(long)(n - RO) * p.ldw_hhT + k];
       }
       W[g][kk] = v;
@@ -285,6 +288,17 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_bwd_kernel(RowResB p) {
   }
 }
 
+
+template <int H>
+__global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) {
+  __shared__ float gbuf[RR_ROWS][4 * H + 24];         // dG_t of the 4 rows (A operand)
+  __shared__ float red[4][RR_ROWS][192];
+  for (int l = a.nl - 1; l >= 0; --l) {
+    rowres_bwd_layer<H, 256>(a.l[l], l > 0, gbuf, red);
+    if (l > 0) { __threadfence(); __syncthreads(); }  // our dx rows are visible to the loads of the next layer; gbuf / red are free again
+  }
+}
+
 }  // namespace
 
 // layers of one pass, sequentially; returns MVAE_ERR_UNSUPPORTED when the shape is not the one this schedule is built for
@@ -327,8 +341,10 @@ int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   if (need && (!d->split_ws || d->split_ws_bytes < need)) return MVAE_ERR_UNSUPPORTED;
   float* dxbuf[2] = {reinterpret_cast<float*>(d->split_ws), reinterpret_cast<float*>(d->split_ws) + (size_t)T * B * H};
   const float* dy = d->dy; long dy_ld = d->dy_ld;
+  RowResBAll all;
+  all.nl = NL;
   for (int l = NL - 1; l >= 0; --l) {
-    RowResB a;
+    RowResB& a = all.l[l];
     a.dy = dy; a.dy_ld = dy_ld;
     a.gates = reinterpret_cast<const float*>(d->gates[l]); a.cs = reinterpret_cast<const float*>(d->cs[l]);
     a.w_ihT = l ? reinterpret_cast<const float*>(d->w_ihT[l]) : nullptr; a.ldw_ihT = d->ldw_ihT[l];
@@ -336,11 +352,9 @@ int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     a.dG = reinterpret_cast<float*>(d->dG[l]); a.ldg = d->ldg;
     a.dx = l ? dxbuf[l & 1] : nullptr;
     a.T = T; a.B = B;
-    dim3 grid((B + RR_ROWS - 1) / RR_ROWS);
-    if (l) hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, true, 256>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lstm_rowres_bwd_kernel<H, false, 320>), grid, dim3(320), 0, st, a);
     dy = a.dx; dy_ld = H;
   }
+  hipLaunchKernelGGL((lstm_rowres_bwd_all_kernel<H>), dim3((B + RR_ROWS - 1) / RR_ROWS), dim3(256), 0, st, all);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
