@@ -143,7 +143,7 @@ def main():
     fwd_us = 1e3 * tag_ms.get("dec_lstm_fwd", float("nan")) / n_launch
     bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-    # Dominant SINGLE kernel (profiles/r01_v7_kernel_stats.csv): the forward wavefront step.  The backward step is two kernels per launch
+    # Dominant SINGLE kernel (profiles/r01_v9_kernel_stats.csv): the forward wavefront step.  The backward step is two kernels per launch
     # since the split-segment schedule (partial-tile GEMM + element-wise gate-derivative kernel), each smaller than the forward step;
     # its pair time is reported alongside.
     dom = "lstm_step_fwd_kernel"
@@ -154,7 +154,7 @@ def main():
     # the profiler on itself); null when the shape differs from the profiled one
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v7_pmc_kernels_T16_B512.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v9_pmc_kernels_T16_B512.json")))
         if B == 512 and args.dtype == "bf16":
             for k, v in pm.items():
                 if dom.replace("_kernel", "") in k:
