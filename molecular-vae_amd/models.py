@@ -486,6 +486,7 @@ class MolDecoder(nn.Module):
         self._pack_key = None
         self._packed = {}
         self.__dict__["_peer"] = None          # weakref to the encoder whose backward runs after ours (set by MolecularVAE)
+        self.__dict__["_z_from_peer"] = False  # True only inside MolecularVAE.forward: z is that encoder's output
         self.__dict__["_side"] = None
         self.overlap_weight_grads = True       # run the weight-gradient GEMMs on a side stream under the encoder's backward
 
@@ -572,6 +573,7 @@ class _DecoderFn(torch.autograd.Function):
         recon = torch.empty(B, Lq, Cv, dtype=f32, device=dev)
         ops.softmax_tb_fwd(logits, Cv, recon, B, Lq, Cv)
         ctx.mod, ctx.gen, ctx.z = mod, ws.generation, z
+        ctx.from_peer = bool(mod.__dict__.get("_z_from_peer", False))
         ctx.save_for_backward(recon)
         return recon
 
@@ -653,7 +655,8 @@ class _DecoderFn(torch.autograd.Function):
         # The two lowest layers' GEMMs are parked (ops.DEFERRED): the peer releases them right before its row-resident LSTM backward,
         # whose 128 workgroups leave half the CUs idle -- the GEMMs fill them instead of running alone later.
         peer = mod.__dict__["_peer"]() if mod.__dict__["_peer"] is not None else None
-        fork = bool(mod.overlap_weight_grads and peer is not None and ctx.needs_input_grad[1] and all(p.grad is None for p in params))
+        fork = bool(mod.overlap_weight_grads and peer is not None and ctx.from_peer and ctx.needs_input_grad[1] and
+                    all(p.grad is None for p in params))
         if fork:
             e1 = torch.cuda.Event(); e1.record()
             side = mod._side_stream(dev)
@@ -703,4 +706,8 @@ class MolecularVAE(nn.Module):
 
     def forward(self, x, eps=None):
         x, mu, logvar = self.encoder(x, eps) if eps is not None else self.encoder(x)
-        return self.decoder(x), mu, logvar
+        self.decoder.__dict__["_z_from_peer"] = True       # this forward's z comes from our encoder: its backward will join / release side work
+        try:
+            return self.decoder(x), mu, logvar
+        finally:
+            self.decoder.__dict__["_z_from_peer"] = False

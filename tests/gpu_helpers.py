@@ -42,7 +42,9 @@ def run_hip(enc, dec, idx, eps, max_len):
     for m in (enc, dec):
         m.zero_grad(set_to_none=True)
     z, mu, logvar = enc(tidx, teps)
+    dec.__dict__["_z_from_peer"] = True           # as MolecularVAE.forward does: z is the paired encoder's output, so the fork is allowed
     recon = dec(z)
+    dec.__dict__["_z_from_peer"] = False
     ohe = torch.nn.functional.one_hot(tidx, C).float()
     loss = mv.bce_kl_loss(recon, ohe, mu, logvar, max_len)
     loss.backward()
