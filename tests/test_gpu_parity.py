@@ -172,7 +172,9 @@ def test_gemm_tn_bf16_tile_variants(shape, bm, monkeypatch):
 @pytest.mark.parametrize("case", [
     (torch.float32, 7, 5, 32, 2, 16, 2e-5),       # tiny, generic register-staged path
     (torch.bfloat16, 7, 5, 32, 2, 16, 3e-2),
-    (torch.float32, 5, 70, 72, 3, 8, 2e-5),       # encoder-like H=72 (ragged K), 3 layers
+    (torch.float32, 5, 70, 72, 3, 8, 2e-5),       # encoder-like H=72, 3 layers: the row-resident schedule (4 rows per workgroup, ragged last one)
+    (torch.float32, 1, 6, 72, 1, 8, 2e-5),        # row-resident edge cases: T = 1, single layer (no input gradient)
+    (torch.float32, 3, 9, 72, 2, 8, 2e-5),
     (torch.bfloat16, 6, 130, 128, 3, 8, 3e-2),    # LDS-direct pipelined path, ragged rows
     (torch.float32, 4, 200, 64, 2, 8, 2e-5),      # pipelined path, f32 MFMA
     (torch.bfloat16, 3, 256, 192, 4, 8, 3e-2),    # 4 layers, 128-row tiles
