@@ -216,10 +216,11 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 # ------------------------------------------------------------------------------------------------ loop body
-def train_step(model, optimizer, loss_function, data, ohe):
-    """train.py:95-104 minus the per-step ``loss.item()`` host sync: returns the loss as a device tensor."""
+def train_step(model, optimizer, loss_function, data, ohe, eps=None):
+    """train.py:95-104 minus the per-step ``loss.item()`` host sync: returns the loss as a device tensor.
+    ``eps`` optionally injects the reparameterisation noise (parity tests); by default the model draws it as models.py:92 does."""
     optimizer.zero_grad(set_to_none=True)
-    recon_batch, mu, logvar = model(data)
+    recon_batch, mu, logvar = model(data) if eps is None else model(data, eps=eps)
     loss = loss_function(recon_batch, ohe, mu, logvar)
     loss.backward()
     optimizer.step()           # clip (max_grad_norm) + Adam fused

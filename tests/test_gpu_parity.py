@@ -366,6 +366,42 @@ def test_full_size_properties_batch512():
     assert np.isfinite(float(gn)) and float(gn) > 0
 
 
+def test_training_trajectory_vs_stock_torch_cpu_port():
+    """Five train.py-style steps (clip 3.0 + Adam 8e-4) of MolecularVAE with FusedAdam (gradients written into the optimiser's flat
+    buffer, weight-gradient GEMMs forked / parked on the side stream) against stock torch.nn modules + torch.optim.Adam on the CPU with
+    the same weights, batches and noise: losses and pre-clip gradient norms must track step by step -- to 1e-6 in f32 mode, and within
+    the bf16 decoder's rounding (2e-4 on the loss) in the default mode."""
+    from oracle import torch_ref
+    Lq, V, B = 120, 26, 16
+    torch.manual_seed(42)
+    m32 = mv.MolecularVAE(i=Lq, c=V, dtype=torch.float32)
+    ref = torch_ref.CpuPort(i=Lq, o=292, c=V)
+    ref.load_state_dict(m32.state_dict())
+    mbf = mv.MolecularVAE(i=Lq, c=V)
+    mbf.load_state_dict(m32.state_dict())
+    m32, mbf = m32.to(dev), mbf.to(dev)
+    o32 = mv.FusedAdam(m32.parameters(), lr=8e-4, max_grad_norm=3.0)
+    obf = mv.FusedAdam(mbf.parameters(), lr=8e-4, max_grad_norm=3.0)
+    ropt = torch.optim.Adam(ref.parameters(), lr=8e-4)
+    loss_fn = mv.make_loss_function(Lq)
+    g = torch.Generator().manual_seed(3)
+    for s in range(5):
+        idx = torch.randint(0, V, (B, Lq), generator=g)
+        eps = 1e-2 * torch.randn(B, 292, generator=g)
+        ohe = torch.nn.functional.one_hot(idx, V).float()
+        l32 = mv.train_step(m32, o32, loss_fn, idx.to(dev), ohe.to(dev), eps=eps.to(dev))
+        lbf = mv.train_step(mbf, obf, loss_fn, idx.to(dev), ohe.to(dev), eps=eps.to(dev))
+        ropt.zero_grad(set_to_none=True)
+        rr, rmu, rlv = ref(idx, eps)
+        rloss = torch_ref.elbo(rr, ohe, rmu, rlv, Lq)
+        rloss.backward()
+        gn = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), 3.0))
+        ropt.step()
+        rl = float(rloss.detach())
+        assert abs(float(l32) - rl) < 1e-6 * abs(rl) and abs(float(o32.last_grad_norm) - gn) < 1e-4 * gn, (s, float(l32), rl)
+        assert abs(float(lbf) - rl) < 2e-4 * abs(rl) and abs(float(obf.last_grad_norm) - gn) < 5e-2 * gn, (s, float(lbf), rl)
+
+
 def test_long_sequence_config_seq256_vocab64():
     """BASELINE.json configs[4] shape (seq_len 256, vocab 64) at a modest batch: f32 path against stock torch.nn modules carrying the same
     weights (oracle/torch_ref.CpuPort), bf16 path against the f32 path, determinism."""
