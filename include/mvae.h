@@ -73,9 +73,10 @@ int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
                  void* ws, size_t ws_bytes, void* stream);
 
 /* bf16 weight gradient AND bias gradient from one pass over dG:  C[M,N] (+)= A^T . B  and  colsum_out[m] (+)= sum_k A[k][m].
- * The column sums come from one extra MFMA per A fragment against a fragment of ones inside the 256 x 256-tile kernel, so they cost
- * no extra HBM traffic (a separate mvae_colsum_t re-reads all of dG).  Only for shapes that kernel serves
- * (mvae_gemm_tn_colsum_supported: N % 256 == 0, >= 32 tiles, K >= 4096); otherwise MVAE_ERR_UNSUPPORTED.  fp32 C, no bias / activation. */
+ * The column sums come from ONE extra MFMA per wave and K-step (an A fragment against a fragment of ones) inside the 256 x 256-tile
+ * kernel, shared out over the 16 waves that hold the same A rows, so they cost no extra HBM traffic (a separate mvae_colsum_t re-reads
+ * all of dG).  Only for shapes that kernel serves with 4 tile columns and split-K (mvae_gemm_tn_colsum_supported: N == 1024, M >= 2048,
+ * K >= 4096); otherwise MVAE_ERR_UNSUPPORTED.  fp32 C, no bias / activation. */
 int mvae_gemm_tn_colsum_supported(int M, int N, int K);
 size_t mvae_gemm_tn_colsum_workspace(int M, int N, int K);
 int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int accumulate,

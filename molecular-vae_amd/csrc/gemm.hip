@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
   if (p.colsum_out && p.colsum_partial) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.M; i += (long)gridDim.x * 256) {
       float v = 0.f;
-      for (int s = 0; s < p.splits; ++s) v += p.colsum_partial[(long)s * p.M + i];
+      for (int s = 0; s < 2 * p.splits; ++s) v += p.colsum_partial[(long)s * p.M + i];      // (split, K-half) partials, fixed order
       p.colsum_out[i] = p.colsum_acc ? p.colsum_out[i] + v : v;
     }
   }
@@ -194,22 +194,17 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(GemmArgs p) {
   PipeSegTN2 s;
   pipe_seg_tn2_init(s, reinterpret_cast<const bf16_t*>(p.A) + kbeg * p.lda, p.lda, m0, reinterpret_cast<const bf16_t*>(p.B) + kbeg * p.ldb, p.ldb, n0,
                     (int)(kend - kbeg), tid);
-  f32x4 accb[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool colsum = COLSUM && p.colsum_out != nullptr && tn == 0 && wn == 0;       // one column of tiles, one column of waves: wave-uniform
-  tile_gemm_tn_256<COLSUM>(smem, s, wm, wn, acc, colsum, accb, tid);
+  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+  // column sums of A: the 16 (tn, wn) pairs of a row panel share the 8 fragments x 2 K-halves (launcher guarantees tiles_n == 4)
+  const int cs_pair = tn * 4 + wn, cs_mi = cs_pair & 7, cs_half = (COLSUM && p.colsum_out != nullptr) ? (cs_pair >> 3) : -1;
+  tile_gemm_tn_256<COLSUM>(smem, s, wm, wn, acc, cs_mi, cs_half, accb, tid);
   const int lr = lane & 15, lq = lane >> 4;
-  if (colsum && lr == 0) {
+  if (COLSUM && cs_half >= 0 && lr == 0) {        // accb[r] (any n column) = sum over this wave's K-half of tile row 16 cs_mi + 4 q + r
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 128 + i * 16 + lq * 4 + r;
-        if (row >= p.M) continue;
-        if (p.splits > 1) p.colsum_partial[(long)split * p.M + row] = accb[i][r];
-        else p.colsum_out[row] = p.colsum_acc ? p.colsum_out[row] + accb[i][r] : accb[i][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm * 128 + cs_mi * 16 + lq * 4 + r;
+      if (row < p.M) p.colsum_partial[((long)split * 2 + cs_half) * p.M + row] = accb[r];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -373,10 +368,13 @@ int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void
 
 // colsum_out (optional, fp32 [M]): out[m] (+)= sum_k A[k][m].  Only the 256 x 256 tile produces it: MVAE_ERR_UNSUPPORTED when the plan
 // for this shape is another tile (the caller then uses mvae_colsum_t).
-bool gemm_tn_colsum_supported(int M, int N, int K) { return make_plan_tn(M, N, K).bm == 512; }
+bool gemm_tn_colsum_supported(int M, int N, int K) {
+  Plan pl = make_plan_tn(M, N, K);
+  return pl.bm == 512 && pl.tiles_n == 4 && pl.splits > 1;       // 16 (tile column, wave column) pairs per row panel; partials summed by the reduction
+}
 size_t gemm_tn_colsum_workspace_bytes(int M, int N, int K) {
   Plan pl = make_plan_tn(M, N, K);
-  return pl.splits > 1 ? (size_t)pl.splits * M * (N + 1) * sizeof(float) : 0;
+  return (size_t)pl.splits * M * (N + 2) * sizeof(float);
 }
 int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
                                const float* bias, int act, int accumulate, float* colsum_out, int colsum_acc, void* ws, size_t ws_bytes,
@@ -395,9 +393,9 @@ int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, con
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
   p.a_group = 0; p.b_group = 0; p.a_gstride = 0; p.b_gstride = 0; p.a_total = (long)K * lda; p.b_total = (long)K * ldb;
   p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = colsum_acc;
-  if (colsum_out && pl.bm != 512) return MVAE_ERR_UNSUPPORTED;
+  if (colsum_out && !(pl.bm == 512 && pl.tiles_n == 4 && pl.splits > 1)) return MVAE_ERR_UNSUPPORTED;
   if (pl.splits > 1) {
-    const size_t need = (size_t)pl.splits * M * (N + (colsum_out ? 1 : 0)) * sizeof(float);
+    const size_t need = (size_t)pl.splits * M * (N + (colsum_out ? 2 : 0)) * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
     p.partial = reinterpret_cast<float*>(ws);
     if (colsum_out) p.colsum_partial = p.partial + (size_t)pl.splits * M * N;

@@ -498,12 +498,12 @@ __device__ __forceinline__ void pipe_tn2_issue(char* smem, const PipeSegTN2& s, 
 }
 
 // smem: 2 x 64 KiB.  wm in {0,1}, wn in {0..3}.
-// COLSUM variant: waves with `colsum` set (wave-uniform) also accumulate accb[mi] = sum_k A[k][m] (every n column identical) with one
-// extra MFMA per A fragment against a fragment of ones -- the bias gradient (column sums of dG) falls out of the weight-gradient GEMM
-// that streams dG anyway.  Its 32 extra accumulator registers are paid for by single-buffering the fragments (256-VGPR budget at two
-// waves per SIMD), so only launches that ask for the column sums use it.
+// COLSUM variant: the column sums of A (sum_k A[k][m], the bias gradient when A = dG) ride along.  The 16 (tile column, wave column)
+// pairs that share one A row panel split its 8 fragments x 2 K-halves between them: pair c does fragment cs_mi = c % 8 of half
+// cs_half = c / 8 with ONE extra MFMA per K-step against a fragment of ones (accb: every n column identical) -- balanced over all
+// waves (+1.5 % MFMAs), no extra pass over dG.  The two halves of a fragment are added by the split-K reduction.
 template <bool COLSUM>
-__device__ __forceinline__ void tile_gemm_tn_256(char* smem, const PipeSegTN2& s, int wm, int wn, f32x4 (&acc)[8][4], bool colsum, f32x4 (&accb)[8],
+__device__ __forceinline__ void tile_gemm_tn_256(char* smem, const PipeSegTN2& s, int wm, int wn, f32x4 (&acc)[8][4], int cs_mi, int cs_half, f32x4& accb,
                                                  int tid) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -518,58 +518,36 @@ __device__ __forceinline__ void tile_gemm_tn_256(char* smem, const PipeSegTN2& s
 #pragma unroll
   for (int i = 0; i < 4; ++i) addrB[i] = (uint32_t)(8 * g + q) * 512u + ((((uint32_t)(wn * 4 + i)) ^ f) << 5) + (uint32_t)pp * 8u + 32768u;
   const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);      // eight bf16 1.0
+  // the fragment whose column sums this wave accumulates is read once more from LDS (its index is only known at run time)
+  uint32_t addrS[1];
+  addrS[0] = (uint32_t)(8 * g + q) * 512u + ((((uint32_t)(wm * 8 + (cs_mi & 7))) ^ f) << 5) + (uint32_t)pp * 8u + (cs_half == 1 ? 32u * 512u : 0u);
   pipe_tn2_issue(smem, s, 0, wave);
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<0>();                                         // my pieces of stage kt have landed
     ws_barrier();                                            // everyone's have; nobody still reads stage kt-1
     if (kt + 1 < nk) pipe_tn2_issue(smem, s, kt + 1, wave);  // into the buffer stage kt-1 used
     const uint32_t st = lds0 + (uint32_t)((kt & 1) * 65536);
-    if constexpr (!COLSUM) {
-      u32x4 a0[8], b0[4], a1[8], b1[4];
-      FragReadTN<0, 8, 512>::template run<0>(a0, addrA, st);
-      FragReadTN<0, 4, 512>::template run<0>(b0, addrB, st);
-      wait_lgkmcnt<0>();
-      FragReadTN<0, 8, 512>::template run<32 * 512>(a1, addrA, st);
-      FragReadTN<0, 4, 512>::template run<32 * 512>(b1, addrB, st);
+    u32x4 a0[8], b0[4], a1[8], b1[4], as[1];
+    FragReadTN<0, 8, 512>::template run<0>(a0, addrA, st);
+    FragReadTN<0, 4, 512>::template run<0>(b0, addrB, st);
+    if constexpr (COLSUM) FragReadTN<0, 1, 512>::template run<0>(as, addrS, st);
+    wait_lgkmcnt<0>();
+    FragReadTN<0, 8, 512>::template run<32 * 512>(a1, addrA, st);
+    FragReadTN<0, 4, 512>::template run<32 * 512>(b1, addrB, st);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
-      wait_lgkmcnt<0>();
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          mma16<bf16_t>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
-    } else {
-      u32x4 a[8], b[4];
-      FragReadTN<0, 8, 512>::template run<0>(a, addrA, st);
-      FragReadTN<0, 4, 512>::template run<0>(b, addrB, st);
-      wait_lgkmcnt<0>();
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          mma16<bf16_t>(__builtin_bit_cast(uint4, a[mi]), __builtin_bit_cast(uint4, b[ni]), acc[mi][ni]);
-      if (colsum) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) mma16<bf16_t>(__builtin_bit_cast(uint4, a[mi]), ones, accb[mi]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      FragReadTN<0, 8, 512>::template run<32 * 512>(a, addrA, st);
-      FragReadTN<0, 4, 512>::template run<32 * 512>(b, addrB, st);
-      wait_lgkmcnt<0>();
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          mma16<bf16_t>(__builtin_bit_cast(uint4, a[mi]), __builtin_bit_cast(uint4, b[ni]), acc[mi][ni]);
-      if (colsum) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) mma16<bf16_t>(__builtin_bit_cast(uint4, a[mi]), ones, accb[mi]);
-      }
+      for (int ni = 0; ni < 4; ++ni)
+        mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
+    if constexpr (COLSUM) {
+      if (cs_half >= 0) mma16<bf16_t>(__builtin_bit_cast(uint4, as[0]), ones, accb);      // wave-uniform
     }
+    wait_lgkmcnt<0>();
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        mma16<bf16_t>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
   }
   ws_barrier();
 }

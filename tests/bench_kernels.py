@@ -69,6 +69,12 @@ if "fwd" in which:
 if "bwd" in which:
     ms = timeit(bwd)
     print(f"bwd : {ms:.3f} ms  {1e3 * ms / nl:.1f} us/launch  {per_t * T / ms / 1e9:.1f} TFLOP/s")
-if "gemm" in which:
+if "gemmcs" in which:
+    db = torch.zeros(G4, device=dev)
+    ms = timeit(lambda: ops.gemm_tn_colsum(dG[1].view(T * B, ldg), hs[0].view(T * B, ldh), dW, db, G4, H, T * B, lda=ldg, ldb=ldh))
+    print(f"gemm+colsum: {ms:.3f} ms  M={G4} N={H} K={T * B}  {2 * G4 * H * T * B / ms / 1e9:.1f} TFLOP/s")
+    ms = timeit(lambda: ops.colsum_t(dG[1].view(T * B, ldg), T * B, G4, db, ldx=ldg))
+    print(f"colsum_t alone: {ms:.3f} ms")
+if "gemm" in which.split(","):
     ms = timeit(gemm)
     print(f"gemm: {ms:.3f} ms  M={G4} N={H} K={T * B}  {2 * G4 * H * T * B / ms / 1e9:.1f} TFLOP/s")
