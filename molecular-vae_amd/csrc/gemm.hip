@@ -474,20 +474,41 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
   const int c4 = (tid & 15) * 4;
   const bool a_vec = (m0 + c4 + 3 < p.M), b_vec = (n0 + c4 + 3 < p.N);     // whole chunk inside the matrix (host checked alignment)
   float4 ra[2], rb[2];
-  auto load_stage = [&](long r0) {
+  // per-thread row offsets, kept incrementally: a runtime integer division per row and stage (grouped operands) costs as many issue
+  // cycles as the stage's MFMAs
+  long oa[2], ob[2]; int ia[2], ib[2];                    // element offset of the row start; position of the row inside its group
+  auto row_init = [&](long r, int group, long gstride, long ld, long& off, int& in_g) {
+    if (group > 0) { const long qg = r / group; in_g = (int)(r - qg * group); off = qg * gstride + (long)in_g * ld; }
+    else { in_g = 0; off = r * ld; }
+  };
+  auto row_step = [&](int group, long gstride, long ld, long& off, int& in_g) {       // advance by TNF_KS rows
+    if (group > 0) {
+      in_g += TNF_KS; off += (long)TNF_KS * ld;
+      while (in_g >= group) { in_g -= group; off += gstride - (long)group * ld; }
+    } else off += (long)TNF_KS * ld;
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long r = rbeg + (tid >> 4) + i * 16;
+    row_init(r, p.a_group, p.a_gstride, p.lda, oa[i], ia[i]);
+    row_init(r, p.b_group, p.b_gstride, p.ldb, ob[i], ib[i]);
+  }
+  auto load_stage = [&](long r0) {                        // stages are loaded in order: the row state advances by one stage per call
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long r = r0 + (tid >> 4) + i * 16;
       float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
       if (r < rend) {
-        const float* pa = A + grow((int)r, p.a_group, p.a_gstride, p.lda) + m0 + c4;
-        const float* pb = B + grow((int)r, p.b_group, p.b_gstride, p.ldb) + n0 + c4;
+        const float* pa = A + oa[i] + m0 + c4;
+        const float* pb = B + ob[i] + n0 + c4;
         if (a_vec) va = *reinterpret_cast<const float4*>(pa);
         else { if (m0 + c4 < p.M) va.x = pa[0]; if (m0 + c4 + 1 < p.M) va.y = pa[1]; if (m0 + c4 + 2 < p.M) va.z = pa[2]; }
         if (b_vec) vb = *reinterpret_cast<const float4*>(pb);
         else { if (n0 + c4 < p.N) vb.x = pb[0]; if (n0 + c4 + 1 < p.N) vb.y = pb[1]; if (n0 + c4 + 2 < p.N) vb.z = pb[2]; }
       }
       ra[i] = va; rb[i] = vb;
+      row_step(p.a_group, p.a_gstride, p.lda, oa[i], ia[i]);
+      row_step(p.b_group, p.b_gstride, p.ldb, ob[i], ib[i]);
     }
   };
   auto store_stage = [&](int buf) {
@@ -514,14 +535,21 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
       if (s + 1 < nst) load_stage(rbeg + (long)(s + 1) * TNF_KS);
       const float* as = &As[cur][fr * TNF_LD + wm * 32 + fc];
       const float* bs = &Bs[cur][fr * TNF_LD + wn * 32 + fc];
+      // all 32 fragment reads of the stage first (one LDS round trip), then 32 MFMAs back to back; left to itself the compiler
+      // alternates two reads / wait / four MFMAs and exposes the LDS latency eight times per stage
+      float af[TNF_KS / 4][2], bf[TNF_KS / 4][2];
 #pragma unroll
       for (int k4 = 0; k4 < TNF_KS / 4; ++k4) {
-        const float a0 = as[k4 * 4 * TNF_LD], a1 = as[k4 * 4 * TNF_LD + 16];
-        const float b0 = bs[k4 * 4 * TNF_LD], b1 = bs[k4 * 4 * TNF_LD + 16];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        af[k4][0] = as[k4 * 4 * TNF_LD]; af[k4][1] = as[k4 * 4 * TNF_LD + 16];
+        bf[k4][0] = bs[k4 * 4 * TNF_LD]; bf[k4][1] = bs[k4 * 4 * TNF_LD + 16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k4 = 0; k4 < TNF_KS / 4; ++k4) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][0], bf[k4][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][0], bf[k4][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][1], bf[k4][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][1], bf[k4][1], acc[1][1], 0, 0, 0);
       }
       if (s + 1 < nst) store_stage(cur ^ 1);
       __syncthreads();
