@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- molecules/s of one full ELBO training step (fwd + loss + bwd + clip + Adam [+ grad all-reduce]).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run with one
-rank per GPU (RCCL).  Rank 0 prints ONE JSON line.  A "step" is train.py:95-104 on one synthetic minibatch of
-BASELINE.json's shape: idx = randint(0, 35, (B, 120)), one-hot target, MolecularVAE(i=120, o=292, c=35) with the
-reference's default init under manual_seed(42), bf16 decoder-LSTM storage / fp32 accumulate + fp32 master weights
-(configs[1]).  Per-GPU batch is fixed (weak scaling); inputs are resident in HBM before the timed region.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it under
+torch.distributed.run with one rank per GPU (RCCL); when it is started directly with --gpus N > 1 and no WORLD_SIZE it starts
+those N ranks itself as a child `python -m torch.distributed.run ...` (decided before anything touches the GPU; never re-execs)
+and fails loudly when the box has fewer than N GPUs or fewer than N ranks join.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json: "molecules/s (ELBO fwd+bwd+step) ... batch 1024, 1/2/4/8 MI355X"): a "step" is train.py:95-104 on one
+synthetic minibatch: idx = randint(0, 35, (b, 120)), one-hot target, MolecularVAE(i=120, o=292, c=35) with the reference's default
+init under manual_seed(42), bf16 decoder-LSTM storage / fp32 accumulate + fp32 master weights.  The GLOBAL batch is fixed at 1024
+(configs[2]) and split over the ranks (b = 1024 / N: strong scaling); `--batch b` fixes the per-GPU batch instead (weak scaling).
+Inputs are resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline     -- the dominant kernel family (decoder LSTM wavefront steps, MFMA bound): algorithmic FLOPs per launch /
+  roofline     -- dominant kernel family (decoder LSTM wavefront forward step, MFMA bound): algorithmic FLOPs per launch /
                   average launch duration measured live with HIP events on the launching stream.
-  cpu_baseline -- oracle/torch_ref.py (the reference architecture on stock torch.nn, CPU) timed on this host's cores
-                  on a bounded sample (rank 0, N=1 only).
+  cpu_baseline -- oracle/torch_ref.py (the reference architecture on stock torch.nn, CPU) timed on this host's cores on a bounded
+                  sample (rank 0, N = 1 only).
+  secondary    -- N = 1 only: the same step at configs[1] (B=512 bf16), at the per-rank shape of configs[2] (b=128 bf16, with its own
+                  roofline object) and in the exact-f32 parity mode (B=1024), each on fewer steps.
+`--model moses` / `--model models2d` bench the mosesvae.VAE path (configs[3]) and the models2d.VAE variant the same way.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,6 +36,7 @@ L_SEQ, VOCAB, LATENT = 120, 35, 292
 H_DEC, NL_DEC = 1024, 4
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md, Peak BF16 MFMA dense
 F32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
 
 
 def flops_per_molecule(L=L_SEQ, C=VOCAB, o=LATENT):
@@ -60,133 +69,241 @@ def host_cores(cap=32):
     return max(1, min(n, cap))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def log(msg):
     if int(os.environ.get("RANK", 0)) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
+def die(msg, code=2):
+    print(f"bench.py: error: {msg}", file=sys.stderr, flush=True)
+    sys.exit(code)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE.json configs[1]: 512)")
+    ap.add_argument("--global-batch", type=int, default=1024, help="global batch, split over the ranks (BASELINE.json: batch 1024; strong scaling)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch; when given the per-GPU work is fixed instead (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="molvae", choices=["molvae", "moses", "models2d"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the B=512 / b=128 / f32 secondary measurements (N = 1)")
+    ap.add_argument("--cpu-steps", type=int, default=16)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the multi-rank "
                                                        "path on a box with fewer GPUs than ranks)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if args.backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())      # rehearsal: ranks may share a GPU
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(args.backend)
-    import molecular_vae_amd as mv
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start the N ranks as a child torch.distributed.run and relay its exit code.  Nothing in this
+    process has touched the GPU (device_count() does not initialise HIP on this image)."""
+    import torch
+    have = torch.cuda.device_count()
+    if args.backend == "nccl" and have < args.gpus:
+        die(f"--gpus {args.gpus} requested but this box has {have} GPU(s); refusing to report a smaller job as n_gpus={args.gpus}")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("starting " + " ".join(cmd))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+# ------------------------------------------------------------------------------------------------------------------ workloads
+class MolVaeWorkload:
+    name = "MolecularVAE(i=120,o=292,c=35) ELBO train step: fwd+loss+bwd+clip(3.0)+Adam(8e-4), synthetic one-hot SMILES [B,120,35]"
+
+    def __init__(self, B, dtype, dev, rank, sync):
+        import torch
+        import molecular_vae_amd as mv
+        self.mv, self.B = mv, B
+        torch.manual_seed(42)                                     # train.py:73
+        self.model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev)
+        self.optimizer = mv.FusedAdam(self.model.parameters(), lr=0.0008, max_grad_norm=3.0, grad_sync=sync)   # train.py:81,102
+        self.loss_function = mv.make_loss_function(L_SEQ)
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.data = torch.randint(0, VOCAB, (B, L_SEQ), generator=g).to(dev)
+        self.ohe = torch.nn.functional.one_hot(self.data, VOCAB).float()    # the (idx, ohe) pair MoleLoader yields, resident in HBM
+        self.model.encoder.lmbd.draw_eps = lambda b, o, d: 1e-2 * torch.randn(b, o, device=d)   # device noise: no H2D copy in the step
+
+    def step(self):
+        return self.mv.train_step(self.model, self.optimizer, self.loss_function, self.data, self.ohe)
+
+    def flops_per_step(self):
+        return flops_per_molecule() * self.B
+
+    def roofline(self, tag_ms, dtype):
+        fwd_f, bwd_f, n_launch = lstm_step_flops(self.B, L_SEQ)
+        fwd_us = 1e3 * tag_ms.get("dec_lstm_fwd", float("nan")) / n_launch
+        bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
+        peak = BF16_DENSE_PEAK_TFLOPS if dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+        # Dominant SINGLE kernel: the forward wavefront step.  The backward step is two kernels per launch (partial-tile GEMM + element-wise
+        # gate-derivative kernel), each smaller than the forward step; its pair time is reported alongside.
+        ach = fwd_f / (fwd_us * 1e-6) / 1e12
+        ach_bwd = bwd_f / (bwd_us * 1e-6) / 1e12
+        return dict(bound="mfma", kernel="lstm_step_fwd_kernel", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                    traffic=pmc_traffic("lstm_step_fwd", self.B, dtype),
+                    launches_per_pass=n_launch, avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
+                    flops_per_launch=dict(lstm_step_fwd=fwd_f, lstm_step_bwd=bwd_f), bwd_pair_tflops=round(ach_bwd, 2),
+                    bwd_pair_frac=round(ach_bwd / peak, 4))
+
+    def config(self, world):
+        return dict(workload=self.name, per_gpu_batch=self.B, global_batch=self.B * world, seq_len=L_SEQ, vocab=VOCAB, latent=LATENT,
+                    parallelism=f"dp{world}")
+
+
+def pmc_traffic(kernel_key, B, dtype):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, KB -> bytes; collected off-line with tests/collect_pmc.sh on the same kernel at the same shape --
+    bench.py cannot run the profiler on itself); null when no profile of this shape exists."""
+    if dtype != "bf16":
+        return None
+    for name in (f"r02_pmc_kernels_T16_B{B}.json", f"r01_v9_pmc_kernels_T16_B{B}.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        for k, v in pm.items():
+            if kernel_key in k and "hbm_read_MB_corrected" in v and "hbm_write_MB" in v:
+                return int((v["hbm_read_MB_corrected"] + v["hbm_write_MB"]) * 1024 * 1024)
+    return None
+
+
+def make_workload(model, B, dtype, dev, rank, sync):
+    if model == "molvae":
+        return MolVaeWorkload(B, dtype, dev, rank, sync)
+    if model == "moses":
+        from bench_extra import MosesWorkload
+        return MosesWorkload(B, dtype, dev, rank, sync)
+    from bench_extra import Models2dWorkload
+    return Models2dWorkload(B, dtype, dev, rank, sync)
+
+
+def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label):
+    """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+    import torch
+    import torch.distributed as dist
     from molecular_vae_amd import ops
-
-    B = args.batch
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    torch.manual_seed(42)                                     # train.py:73
-    model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=dtype).to(dev)
-    sync = mv.GradSync() if world > 1 else None
-    optimizer = mv.FusedAdam(model.parameters(), lr=0.0008, max_grad_norm=3.0, grad_sync=sync)   # train.py:81,102
-    loss_function = mv.make_loss_function(L_SEQ)
-    g = torch.Generator().manual_seed(1234 + rank)
-    data = torch.randint(0, VOCAB, (B, L_SEQ), generator=g).to(dev)
-    ohe = torch.nn.functional.one_hot(data, VOCAB).float()    # the (idx, ohe) pair MoleLoader yields, resident in HBM
-    model.encoder.lmbd.draw_eps = lambda b, o, d: 1e-2 * torch.randn(b, o, device=d)   # device noise: no H2D copy in the step
-
-    def step():
-        return mv.train_step(model, optimizer, loss_function, data, ohe)
-
-    log(f"model built, B={B} dtype={args.dtype} world={world}")
-    for i in range(args.warmup):
-        loss = step()
+    wl = make_workload(model, B, dtype, dev, rank, sync)
+    log(f"[{label}] model built, per-GPU batch {B}, dtype {dtype}, world {world}")
+    for i in range(warmup):
+        loss = wl.step()
         if i == 0:
             torch.cuda.synchronize()
-            log(f"first step done, loss={float(loss):.5f}")
+            log(f"[{label}] first step done, loss={float(loss):.5f}")
     torch.cuda.synchronize()
-    log("warm-up done")
     if world > 1:
         dist.barrier()
     ops.PROFILE = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for _ in range(steps):
+        loss = wl.step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    ms_per_step = 1e3 * dt / args.steps
-    value = B * world * args.steps / dt
-
-    # roofline of the dominant kernel family, measured live (HIP events on the launching stream)
-    fwd_f, bwd_f, n_launch = lstm_step_flops(B, L_SEQ)
+    ms = 1e3 * dt / steps
+    log(f"[{label}] timed region done: {ms:.2f} ms/step")
     tag_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in prof.items()}
-    fwd_us = 1e3 * tag_ms.get("dec_lstm_fwd", float("nan")) / n_launch
-    bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
-    peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-    # Dominant SINGLE kernel (profiles/r01_v9_kernel_stats.csv): the forward wavefront step.  The backward step is two kernels per launch
-    # since the split-segment schedule (partial-tile GEMM + element-wise gate-derivative kernel), each smaller than the forward step;
-    # its pair time is reported alongside.
-    dom = "lstm_step_fwd_kernel"
-    ach = fwd_f / (fwd_us * 1e-6) / 1e12
-    ach_bwd = bwd_f / (bwd_us * 1e-6) / 1e12
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB -> bytes) on the same
-    # kernel at the same shape, collected off-line with tests/bench_kernels.py and committed under profiles/ (bench.py cannot run
-    # the profiler on itself); null when the shape differs from the profiled one
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v9_pmc_kernels_T16_B512.json")))
-        if B == 512 and args.dtype == "bf16":
-            for k, v in pm.items():
-                if dom.replace("_kernel", "") in k:
-                    traffic = int((v["hbm_read_MB_corrected"] + v["hbm_write_MB"]) * 1024 * 1024)
-    except Exception:
-        traffic = None
-    roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    traffic=traffic,
-                    launches_per_pass=n_launch, avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
-                    flops_per_launch=dict(lstm_step_fwd=fwd_f, lstm_step_bwd=bwd_f),
-                    bwd_pair_tflops=round(ach_bwd, 2),
-                    phase_ms={k: round(v, 3) for k, v in tag_ms.items()},
-                    whole_step_tflops=round(flops_per_molecule() * B * args.steps / dt / 1e12 / world * world, 2))
+    roof = wl.roofline(tag_ms, dtype)
+    roof["phase_ms"] = {k: round(v, 3) for k, v in tag_ms.items()}
+    roof["whole_step_tflops"] = round(wl.flops_per_step() * steps / dt / 1e12, 2)
+    res = dict(value=round(B * world * steps / dt, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup, dtype=dtype,
+               final_loss=round(float(loss), 6), roofline=roof, config=wl.config(world))
+    del wl
+    ops.release_caches()
+    torch.cuda.empty_cache()
+    return res
 
-    out = dict(metric="molecules/s (ELBO fwd+bwd+step)", value=round(value, 1), unit="molecules/s", n_gpus=world,
-               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
-               config=dict(workload="MolecularVAE(i=120,o=292,c=35) ELBO train step: fwd+loss+bwd+clip(3.0)+Adam(8e-4), "
-                                    "synthetic one-hot SMILES [B,120,35]", per_gpu_batch=B, global_batch=B * world,
-                           seq_len=L_SEQ, vocab=VOCAB, parallelism=f"dp{world}", final_loss=round(float(loss), 6)),
-               roofline=roofline)
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        die("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                           # never returns
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        die(f"--gpus {args.gpus} but WORLD_SIZE={world}: every GPU of the job must run one rank")
+    bad = sorted(k for k in os.environ if k.startswith("MVAE_"))
+    if bad:
+        die(f"tuning variables set in the environment ({', '.join(bad)}): the bench measures the default build only")
+    import torch
+    if args.backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())      # rehearsal: ranks may share a GPU
+    elif torch.cuda.device_count() <= local_rank:
+        die(f"rank {rank}: no GPU {local_rank} on this box ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    sync = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            die(f"{dist.get_world_size()} ranks joined, --gpus {args.gpus}")
+        import molecular_vae_amd as mv
+        sync = mv.GradSync()
+    if args.batch > 0:
+        B, scaling = args.batch, "weak"
+    else:
+        if args.global_batch % world:
+            die(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+        B, scaling = args.global_batch // world, "strong"
+
+    main_res = measure(args.model, B, args.dtype, args.steps, args.warmup, dev, rank, world, sync, "main")
+    metric = {"molvae": "molecules/s (ELBO fwd+bwd+step)", "moses": "molecules/s (mosesvae.VAE KL+CE fwd+bwd+step)",
+              "models2d": "molecules/s (models2d.VAE ELBO fwd+bwd+step)"}[args.model]
+    cfg = main_res["config"]; cfg["final_loss"] = main_res["final_loss"]
+    out = dict(metric=metric, value=main_res["value"], unit="molecules/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=main_res["ms_per_step"], higher_is_better=True, scaling=scaling, vs_baseline=None, dtype=args.dtype,
+               data="synthetic", config=cfg, roofline=main_res["roofline"])
+
+    if world == 1 and args.model == "molvae" and not args.no_secondary and args.batch == 0 and args.dtype == "bf16":
+        sec = {}
+        for label, b, dt_, st, wu in (("configs1_B512_bf16", 512, "bf16", 10, 3), ("configs2_per_rank_b128_bf16", 128, "bf16", 20, 5),
+                                      ("parity_mode_B1024_f32", args.global_batch, "f32", 3, 1)):
+            r = measure("molvae", b, dt_, st, wu, dev, rank, 1, None, label)
+            sec[label] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=st, warmup=wu, dtype=dt_,
+                              per_gpu_batch=b, final_loss=r["final_loss"], roofline=r["roofline"])
+        out["secondary"] = sec
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref
         cores = host_cores()
         log(f"cpu baseline on {cores} threads ...")
         r = torch_ref.time_cpu_training(batch=32, steps=args.cpu_steps, warmup=2, threads=cores, log=log)
         out["cpu_baseline"] = dict(value=round(r["molecules_per_s"], 2), unit="molecules/s", cores=r["threads"], kind="port",
-                                   sample=f"{args.cpu_steps} train steps (after 2 warm-up) of the same model at batch 32 "
+                                   cpu_model=cpu_model(),
+                                   sample=f"{args.cpu_steps} train steps (after 2 warm-up) of the MolecularVAE step at batch 32 "
                                           f"(BASELINE.json configs[0]), torch.nn CPU modules, {r['s_per_step']:.2f} s/step")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -120,6 +120,8 @@ size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W);
  *   hs[l]     [T][B][ldh]   dtype   layer outputs h_t          (hs[layers-1] is the stack output)
  *   cs[l]     [T][B][H]     dtype   cell states as the backward pass reads them (LSTM only)
  *   gates[l]  [T][B][G*H]   dtype   post-activation gates i,f,g,o (LSTM) / r,z,n,(W_hn h + b_hn) (GRU)
+ *   A forward-only call (evaluation under no_grad, train.py:120-153) passes gates[l] == cs[l] == NULL for EVERY layer: the
+ *   kernels then skip the saved-state stores (12 of the 16 bytes written per (row, unit, step)); hs / cstate are still written.
  *   cstate[l] [2][B][H]     fp32    scratch: the recurrent cell state itself stays fp32 (ping-pong over t)
  * lengths (GRU path): per-sequence valid length, sorted descending (pack_sequence semantics: a finished
  * sequence keeps its last state and emits zeros); NULL = all T.

@@ -10,8 +10,11 @@ from .functional import bce_kl_loss, make_loss_function  # noqa: F401
 from . import mosesvae, vocab, data  # noqa: F401
 from .data import MoleLoader, DeviceDataset, build_vocab, encode_smiles  # noqa: F401
 from .vocab import CharVocab, OneHotVocab  # noqa: F401
-from .train import FusedAdam, GradSync, ShardedSampler, shard_batch, train_step, exact_match_accuracy  # noqa: F401
+from .train import (FusedAdam, GradSync, ShardedSampler, shard_batch, train_step, exact_match_accuracy, evaluate, save_checkpoint,  # noqa: F401
+                    load_checkpoint, strip_module_prefix, KLAnnealer, CosineAnnealingLRWithRestart, cosine_lr_with_restart,
+                    moses_train_step, moses_train_epoch)
 
 __all__ = ["mosesvae", "vocab", "data", "MoleLoader", "DeviceDataset", "build_vocab", "encode_smiles", "CharVocab", "OneHotVocab", "MolecularVAE", "MolEncoder", "MolDecoder", "Lambda", "ConvSELU", "SELU", "TimeDistributed", "Repeat",
            "Flatten", "bce_kl_loss", "make_loss_function", "FusedAdam", "GradSync", "ShardedSampler", "shard_batch",
-           "train_step", "exact_match_accuracy"]
+           "train_step", "exact_match_accuracy", "evaluate", "save_checkpoint", "load_checkpoint", "strip_module_prefix", "KLAnnealer",
+           "CosineAnnealingLRWithRestart", "cosine_lr_with_restart", "moses_train_step", "moses_train_epoch"]

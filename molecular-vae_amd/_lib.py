@@ -4,11 +4,14 @@ The product path has NO CPU fallback: if the HIP library is missing or a call fa
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvae_hip.so")
+# MVAE_LIB: absolute path of a diagnostic build (csrc/build.sh tune -> libmvae_hip_tune.so) for timing decompositions; bench.py refuses to
+# run with any MVAE_* variable set, so a measured number always comes from the product library.
+LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 
 MVAE_F32, MVAE_BF16 = 0, 1
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
@@ -153,24 +156,49 @@ def dt_code(dtype):
     raise MvaeError(f"unsupported dtype {dtype}")
 
 
-# bumped by in-place parameter updates that bypass torch's version counters (FusedAdam) so that the
-# packed (bf16 / transposed) weight shadows are refreshed
+# Bumped by in-place parameter updates that bypass torch's version counters (FusedAdam.step, load_state_dict) so that the packed
+# (bf16 / transposed) weight shadows are refreshed.  Code that edits parameter storage by hand (``p.data[...] = ...`` through a view
+# torch does not track) must do ``_lib.PARAM_EPOCH[0] += 1`` itself.
 PARAM_EPOCH = [0]
 
-# Gradient sinks: id(parameter) -> (optimizer, flat gradient buffer, offset, numel).  Registered by train.FusedAdam so that the
-# modules' backward passes write parameter gradients straight into the optimiser's flat buffer (no gather copy) and can start the
-# data-parallel all-reduce of a finished range while the rest of backward is still running.
-GRAD_SINKS = {}
+# Gradient sinks.  train.FusedAdam registers, ON each parameter object (attribute ``_mvae_sink``), where that parameter's gradient
+# lives inside the optimiser's flat fp32 gradient buffer: (weakref(optimizer), flat, offset, numel).  The modules' backward passes
+# then write parameter gradients straight into that buffer (no gather copy) and can start the data-parallel all-reduce of a finished
+# range while the rest of backward is still running.  The entry dies with the parameter; a dead optimiser's entry is dropped on sight.
+_SINK_ATTR = "_mvae_sink"
+
+
+def register_grad_sink(p, owner, flat, off):
+    setattr(p, _SINK_ATTR, (weakref.ref(owner), flat, off, p.numel()))
+
+
+def clear_grad_sink(p):
+    if hasattr(p, _SINK_ATTR):
+        delattr(p, _SINK_ATTR)
+
+
+def _sink(p):
+    e = getattr(p, _SINK_ATTR, None)
+    if e is None:
+        return None
+    owner = e[0]()
+    if owner is None:
+        delattr(p, _SINK_ATTR)
+        return None
+    return owner, e[1], e[2], e[3]
 
 
 def grad_sink_range(params):
     """(owner, flat, lo, hi) when `params` occupy one contiguous, in-order range of one registered flat buffer; else None."""
-    if not params or id(params[0]) not in GRAD_SINKS:
+    if not params:
         return None
-    owner, flat, lo, _ = GRAD_SINKS[id(params[0])]
+    first = _sink(params[0])
+    if first is None:
+        return None
+    owner, flat, lo, _ = first
     off = lo
     for q in params:
-        e = GRAD_SINKS.get(id(q))
+        e = _sink(q)
         if e is None or e[0] is not owner or e[1] is not flat or e[2] != off:
             return None
         off += e[3]

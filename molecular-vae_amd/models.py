@@ -496,7 +496,9 @@ class MolDecoder(nn.Module):
         return self.__dict__["_side"]
 
     def forward(self, x):
-        return _DecoderFn.apply(self, x, *list(self.parameters()))
+        # under no_grad (evaluation, train.py:120-153 / sampling from a latent, train_sample.py:32) nothing is saved for backward
+        infer = not torch.is_grad_enabled()
+        return _DecoderFn.apply(self, x, infer, *list(self.parameters()))
 
     def _pack(self, dev):
         params = list(self.parameters())
@@ -538,7 +540,7 @@ class MolDecoder(nn.Module):
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, z, *params):
+    def forward(ctx, mod, z, infer, *params):
         dev = z.device
         _require_cuda(dev, "MolDecoder")
         z = z.contiguous().float()
@@ -562,8 +564,8 @@ class _DecoderFn(torch.autograd.Function):
         # K7: 4-layer LSTM wavefront
         ldh = H + _LDPAD
         hs = [ws.get(f"hs{l}", (Lq, B, ldh), dt, dev) for l in range(NL)]
-        cs = [ws.get(f"cs{l}", (Lq, B, H), dt, dev) for l in range(NL)]
-        gates = [ws.get(f"gates{l}", (Lq, B, G4), dt, dev) for l in range(NL)]
+        cs = [None if infer else ws.get(f"cs{l}", (Lq, B, H), dt, dev) for l in range(NL)]
+        gates = [None if infer else ws.get(f"gates{l}", (Lq, B, G4), dt, dev) for l in range(NL)]
         cstate = [ws.get(f"cstate{l}", (2, B, H), f32, dev) for l in range(NL)]
         ops.rnn_fwd(L.CELL_LSTM, dt, Lq, B, H, gx0, 0, P["Wih"], [P["ldw"]] * NL, P["Whh"], [P["ldw"]] * NL, [None] + P["bias"][1:],
                     hs, ldh, cs, gates, cstate, tag="dec_lstm_fwd")
@@ -572,7 +574,7 @@ class _DecoderFn(torch.autograd.Function):
         ops.gemm_nt(hs[-1].view(TB, ldh), P["Wout"], logits, TB, Cv, H, bias=om.bias)
         recon = torch.empty(B, Lq, Cv, dtype=f32, device=dev)
         ops.softmax_tb_fwd(logits, Cv, recon, B, Lq, Cv)
-        ctx.mod, ctx.gen, ctx.z = mod, ws.generation, z
+        ctx.mod, ctx.gen, ctx.z = mod, (-1 if infer else ws.generation), z     # a forward-only pass saved nothing: backward refuses
         ctx.from_peer = bool(mod.__dict__.get("_z_from_peer", False))
         ctx.save_for_backward(recon)
         return recon
@@ -643,9 +645,11 @@ class _DecoderFn(torch.autograd.Function):
                 nlow = min(int(os.environ.get("MVAE_DEFER_LAYERS", "2")), NL - 1)
                 layers = range(NL) if part is None else (range(nlow, NL) if part == 0 else range(nlow))
                 _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers)
-                if part != 0 and sink is not None and getattr(sink[0], "grad_sync", None) is not None:
+                if part == 1 and sink is not None and getattr(sink[0], "grad_sync", None) is not None:
                     # everything from gru.weight_hh_l0 to the end of our range is final on this stream: all-reduce it now, under the
-                    # encoder's backward (weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step())
+                    # encoder's backward (weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step()).
+                    # Fork path only: there the gradients are handed over by ASSIGNMENT (p.grad = view of the flat buffer), so what
+                    # step() sees is the reduced buffer; through autograd's AccumulateGrad a clone could hide it (FusedAdam.gather_grads)
                     lo = sink[2] + offs["gru.weight_hh_l0"]
                     sink[0].grad_sync.start_early(sink[1], lo, sink[3])
 
@@ -690,8 +694,8 @@ class _DecoderFn(torch.autograd.Function):
             # gradients are still being written on the side stream: hand them over by assignment (autograd must not touch them)
             for n, p in zip(names, params):
                 p.grad = grads[n]
-            return (None, dz) + (None,) * len(names)
-        return (None, dz) + tuple(grads[n] for n in names)
+            return (None, dz, None) + (None,) * len(names)
+        return (None, dz, None) + tuple(grads[n] for n in names)
 
 
 # ----------------------------------------------------------------------------------------------- VAE

@@ -41,6 +41,10 @@ class VAE(nn.Module):
         for ss in ("bos", "eos", "unk", "pad"):
             setattr(self, ss, getattr(vocab, ss))
         n_vocab, d_emb = len(vocab), vocab.vectors.size(1)
+        if d_emb != n_vocab or vocab.vectors.size(0) != n_vocab:
+            # the kernels fold the (identity-initialised, trainable) embedding into the layer-0 projections as a [V, V] table
+            raise ValueError(f"mosesvae.VAE needs a one-hot vocabulary (vocab.vectors [{n_vocab}, {n_vocab}], mosesvae.py:48-50); "
+                             f"got {tuple(vocab.vectors.shape)}")
         self.x_emb = EmbeddingWeights(n_vocab, d_emb)
         self.x_emb.padding_idx = self.pad
         self.x_emb.weight.data.copy_(vocab.vectors)                 # mosesvae.py:50 (overwrites the zeroed pad row too)

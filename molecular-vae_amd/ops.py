@@ -64,6 +64,12 @@ def join_pending():
         torch.cuda.current_stream().wait_event(PENDING.pop())
 
 
+def release_caches():
+    """Drop the op-internal scratch buffers and any forgotten fork bookkeeping (between benchmark configurations / models)."""
+    join_pending()
+    Scratch._bufs.clear()
+
+
 class Scratch:
     """Grow-only byte scratch for split-K slabs and op-internal temporaries (one per device AND stream: two streams must
     never share split-K slabs)."""
@@ -292,7 +298,8 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
     _fill(d.hs, hs); d.ldh = ldh
     if cs is not None:
         _fill(d.cs, cs)
-    _fill(d.gates, gates)
+    if gates is not None:
+        _fill(d.gates, gates)
     if cstate is not None:
         _fill(d.cstate, cstate)
     d.zero_padded_k = 1 if zero_padded_k else 0

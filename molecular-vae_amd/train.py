@@ -29,11 +29,13 @@ class GradSync:
     per-link transfer well above the latency floor while letting bucket k+1 overlap bucket k's reduction.
     """
 
-    def __init__(self, bucket_bytes=32 << 20, group=None):
+    def __init__(self, bucket_bytes=32 << 20, group=None, early=True):
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.group = group
+        self.allow_early = early  # False: every range is reduced in step() (needed when parameter hooks clone gradients)
         self.handles = []
         self.early = []          # [(flat, lo, hi)] ranges whose all-reduce was started from inside backward (this step)
+        self.stats = dict(buckets=0, early_ranges=0)     # running totals (tests / logs)
 
     @property
     def world(self):
@@ -44,6 +46,7 @@ class GradSync:
             return
         n = flat.numel()
         for off in range(0, n, self.bucket_elems):
+            self.stats["buckets"] += 1
             self.handles.append(dist.all_reduce(flat[off:min(n, off + self.bucket_elems)], op=dist.ReduceOp.SUM,
                                                 group=self.group, async_op=True))
 
@@ -51,10 +54,11 @@ class GradSync:
         """Called from a module's backward once flat[lo:hi] is final on the CURRENT stream (the collective is ordered after
         that stream's work): the all-reduce then runs under the rest of backward.  Every rank issues the same calls in the
         same order (same model, same code path)."""
-        if self.world == 1:
+        if self.world == 1 or not self.allow_early:
             return
         self.start(flat[lo:hi])
         self.early.append((flat, lo, hi))
+        self.stats["early_ranges"] += 1
 
     def start_rest(self, flat):
         """All-reduce whatever part of `flat` start_early has not covered."""
@@ -115,8 +119,13 @@ class FusedAdam(torch.optim.Optimizer):
     ``mvae_sumsq`` + ``mvae_clip_adam`` -- no host synchronisation anywhere.
     """
 
+    # torch.optim.Adam's remaining hyper-parameters at their inert values: kept in every param_group so that ``state_dict()`` loads into
+    # ``torch.optim.Adam`` (train.py:81,173) and the reverse; step() refuses any other value.
+    _ADAM_INERT = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                       decoupled_weight_decay=False)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, grad_sync=None):
-        defaults = dict(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm)
+        defaults = dict(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, **self._ADAM_INERT)
         super().__init__(params, defaults)
         self.grad_sync = grad_sync
         self._flat = []
@@ -142,8 +151,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat.append(dict(params=ps, p=pflat, m=m, v=v, g=g, partial=torch.zeros(nparts, device=dev),
                                    norm=torch.zeros(1, device=dev), step=0))
             off = 0
-            for p in ps:                 # modules may write their gradients straight into g (see _lib.GRAD_SINKS)
-                L.GRAD_SINKS[id(p)] = (self, g, off, p.numel())
+            for p in ps:                 # modules may write their gradients straight into g (see _lib.register_grad_sink)
+                L.register_grad_sink(p, self, g, off)
                 off += p.numel()
         L.PARAM_EPOCH[0] += 1
 
@@ -155,6 +164,7 @@ class FusedAdam(torch.optim.Optimizer):
     def gather_grads(self):
         """Copy every ``p.grad`` into the flat gradient buffer (missing grads count as zero); returns the flats."""
         outs = []
+        early = self.grad_sync.early if self.grad_sync is not None else None
         for f in self._flat:
             if f is None:
                 continue
@@ -164,6 +174,11 @@ class FusedAdam(torch.optim.Optimizer):
                 if p.grad is None:
                     f["g"][off:off + k].zero_()
                 elif p.grad.data_ptr() != f["g"].data_ptr() + 4 * off or not p.grad.is_contiguous():
+                    # autograd cloned the gradient (a tensor hook, a second reference) instead of adopting the sink view
+                    if early and any(fl is f["g"] and lo < off + k and off < hi for fl, lo, hi in early):
+                        raise L.MvaeError("a gradient inside a range whose all-reduce was already started from backward lives outside the "
+                                          "flat gradient buffer (parameter hooks / retained grads clone it): the reduced and the local "
+                                          "gradient would be mixed.  Remove the hook or build GradSync(early=False).")
                     views.append((off, k, p.grad))          # (a gradient written in place through the sink needs no copy)
                 off += k
             if views:
@@ -188,6 +203,8 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             f["step"] += 1
             b1, b2 = group["betas"]
+            if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
+                raise L.MvaeError("FusedAdam implements plain Adam (train.py:81): weight_decay / amsgrad / maximize are not supported")
             if f["p"].device.type != "cuda":
                 raise L.MvaeError("FusedAdam.step runs on the MI355X only (no CPU fallback)")
             ops.sumsq(f["g"], f["partial"])
@@ -199,20 +216,59 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     def load_state_dict(self, state_dict):
+        """Accepts a FusedAdam or a ``torch.optim.Adam`` state dict (train.py:173 ``optimizer_state_dict``): same ``state`` layout
+        (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter index); hyper-parameters present in the dict override ours."""
         sd_groups = state_dict["param_groups"]
+        if len(sd_groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
         for group, sg in zip(self.param_groups, sd_groups):
-            for k in ("lr", "betas", "eps", "max_grad_norm"):
+            if len(sg["params"]) != len(group["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            for k in ("lr", "betas", "eps", "max_grad_norm", "initial_lr"):
                 if k in sg:
-                    group[k] = sg[k]
+                    group[k] = tuple(sg[k]) if k == "betas" else sg[k]
         idx = 0
         for group, f in zip(self.param_groups, self._flat):
             for p in group["params"]:
                 st = state_dict["state"].get(idx)
-                if st is not None and f is not None:
+                if st is not None and f is not None and p in self.state:
                     self.state[p]["exp_avg"].copy_(st["exp_avg"]); self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
                     self.state[p]["step"] = torch.as_tensor(float(st["step"]))
                     f["step"] = int(float(st["step"]))
                 idx += 1
+
+
+class CosineAnnealingLRWithRestart:
+    """moses_train_distrib.py:61-89, same state machine: period 10 epochs, lr_end 1e-4, no period growth; constructing it performs the
+    first ``step()`` (as ``_LRScheduler.__init__`` does), so the very first epoch already runs at the k = 1 point of the cosine."""
+
+    def __init__(self, optimizer):
+        self.optimizer = optimizer
+        self.n_period, self.n_mult, self.lr_end = 10, 1, 1e-4
+        self.current_epoch, self.t_end = 0, self.n_period
+        for g in optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
+        self.last_epoch = -1
+        self.step()
+
+    def get_lr(self):
+        return [cosine_lr_with_restart(b, self.current_epoch, self.t_end, self.lr_end) for b in self.base_lrs]
+
+    def step(self, epoch=None):
+        self.last_epoch = self.last_epoch + 1 if epoch is None else epoch
+        self.current_epoch += 1
+        for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
+            g["lr"] = lr
+        if self.current_epoch == self.t_end:
+            self.current_epoch = 0
+            self.t_end = self.n_mult * self.t_end
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
 
 
 # ------------------------------------------------------------------------------------------------ loop body
@@ -248,3 +304,90 @@ class KLAnnealer:
     def __call__(self, i):
         k = (i - self.i_start) if i >= self.i_start else 0
         return self.w_start + k * self.inc
+
+
+# ------------------------------------------------------------------------------------------------ evaluation / checkpoints
+@torch.no_grad()
+def evaluate(model, loss_function, batches):
+    """``test(epoch)`` of train.py:120-153 without the logging: forward-only over `batches` of ``(idx, ohe)``, returns
+    ``(mean loss per batch, exact-match accuracy over all sequences)`` as Python floats (one host sync at the end).  Runs under
+    ``no_grad``: the decoder then skips the 16 B per (row, unit, step) of saved gate / cell state it writes for backward."""
+    was_training = model.training
+    model.eval()
+    total, right, n_seq, n = None, None, 0, 0
+    for data, ohe in batches:
+        recon, mu, logvar = model(data)
+        loss = loss_function(recon, ohe, mu, logvar)
+        acc = (recon.argmax(dim=2) == data).all(dim=1).sum()
+        total = loss if total is None else total + loss
+        right = acc if right is None else right + acc
+        n_seq += data.shape[0]; n += 1
+    model.train(was_training)
+    if n == 0:
+        return float("nan"), float("nan")
+    return float(total) / n, float(right) / n_seq
+
+
+def strip_module_prefix(state_dict):
+    """Keys saved from ``nn.DataParallel(model)`` (train_distributed.py:72,145-151) carry a ``module.`` prefix; the strip of
+    mosesanalyize.py:171-173, applied only to keys that have it."""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+
+def save_checkpoint(path, model, optimizer, epoch, charset, max_len, latent_size=None):
+    """The dictionary of train.py:170-177 (``latent_size`` is absent in train_distributed.py:145-151)."""
+    lr = optimizer.param_groups[-1]["lr"]
+    d = {"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(), "epoch": epoch,
+         "charset": charset, "max_len": max_len, "lr": lr}
+    if latent_size is not None:
+        d["latent_size"] = latent_size
+    torch.save(d, path)
+    return d
+
+
+def load_checkpoint(path_or_dict, model, optimizer=None, map_location="cpu"):
+    """Inverse of ``save_checkpoint``; also takes the reference's own files (same keys; ``module.``-prefixed model keys accepted).
+    The reference has no resume path -- this is the loader its ``train_sample.py:16-19`` spells out by hand."""
+    ck = torch.load(path_or_dict, map_location=map_location, weights_only=False) if isinstance(path_or_dict, (str, bytes)) or hasattr(path_or_dict, "read") else path_or_dict
+    model.load_state_dict(strip_module_prefix(ck["model_state_dict"]))
+    L.PARAM_EPOCH[0] += 1
+    if optimizer is not None and "optimizer_state_dict" in ck:
+        optimizer.load_state_dict(ck["optimizer_state_dict"])
+    return ck
+
+
+# ------------------------------------------------------------------------------------------------ MOSES loop body
+def moses_train_step(model, optimizer, kl_weight, batch, eps=None):
+    """moses_train_distrib.py:287-299 in the 6-tuple form of moses_train_distrib_logp.py:321-345: ``loss = kl_weight * kl + recon``,
+    backward, ``clip_grad_norm_(50)`` (the optimiser's ``max_grad_norm``) and ``Adam.step()`` -- without the per-step ``.item()``
+    syncs.  Returns device scalars ``(loss, kl, recon)``."""
+    optimizer.zero_grad(set_to_none=True)
+    kl_loss, recon_loss, _, _, _, _ = model(batch) if eps is None else model(batch, eps=eps)
+    loss = kl_weight * kl_loss + recon_loss
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), kl_loss.detach(), recon_loss.detach()
+
+
+def moses_train_epoch(model, epoch, batches, kl_weight, optimizer=None, log_every=0, log=print):
+    """``_train_epoch`` (moses_train_distrib.py:200-258): train when an optimiser is given, else evaluate; returns the same ``postfix``
+    dictionary (epoch means instead of the reference's 1000-entry circular-buffer means, which average over unwritten zeros)."""
+    model.train(optimizer is not None)
+    sums, n = None, 0
+    for i, batch in enumerate(batches):
+        if optimizer is not None:
+            vals = moses_train_step(model, optimizer, kl_weight, batch)
+        else:
+            with torch.no_grad():
+                kl, rec, _, _, _, _ = model(batch)
+            vals = (kl_weight * kl + rec, kl, rec)
+        v = torch.stack([x.float() for x in vals])
+        sums = v if sums is None else sums + v
+        n += 1
+        if log_every and i % log_every == 0:
+            cur = (sums / n).tolist()
+            log(f"epoch {epoch} it {i}: loss={cur[0]:.5f} (kl={cur[1]:.5f} recon={cur[2]:.5f}) klw={kl_weight:.5f}")
+    mean = (sums / max(n, 1)).tolist() if sums is not None else [float("nan")] * 3
+    lr = optimizer.param_groups[0]["lr"] if optimizer is not None else None
+    return {"epoch": epoch, "kl_weight": kl_weight, "lr": lr, "kl_loss": mean[1], "recon_loss": mean[2], "loss": mean[0],
+            "mode": "Eval" if optimizer is None else "Train"}

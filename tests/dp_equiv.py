@@ -28,7 +28,7 @@ if args.compare:
         for x, y in zip(a[k], b[k]):
             rel = abs(x - y) / (abs(x) + 1e-30)
             print(f"{k}: {x:.8f} vs {y:.8f}  rel {rel:.2e}")
-            ok = ok and rel < 2e-4
+            ok = ok and rel < 2e-6
     print("EQUIVALENT" if ok else "MISMATCH")
     sys.exit(0 if ok else 1)
 
@@ -53,7 +53,7 @@ per = gb // world
 sl = slice(rank * per, (rank + 1) * per)
 data = data_all[sl].to(dev)
 ohe = torch.nn.functional.one_hot(data, VOCAB).float()
-out = dict(loss=[], psum=[], gnorm=[])
+out = dict(loss=[], psum=[], gnorm=[], world=world)
 for s in range(args.steps):
     eps = eps_all[s, sl].to(dev)
     opt.zero_grad(set_to_none=True)
@@ -67,6 +67,7 @@ for s in range(args.steps):
     out["loss"].append(float(lt))
     out["gnorm"].append(float(opt.last_grad_norm))
     out["psum"].append(float(sum(p.detach().abs().sum() for p in model.parameters())))
+out["early_ranges"] = sync.stats["early_ranges"] if sync is not None else 0
 if rank == 0 and args.out:
     json.dump(out, open(args.out, "w"))
     print(out)

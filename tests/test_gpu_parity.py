@@ -334,16 +334,18 @@ def test_g4_clip_adam_trajectory(golden_dir):
             assert abs(np.sqrt((a ** 2).sum()) - float(g["fnorm." + pre + k])) < 1e-4 * (1 + float(g["fnorm." + pre + k])), k
 
 
-def test_full_size_properties_batch512():
-    """BASELINE.json configs[1] size (B=512, L=120, C=35): properties that need no oracle run.
+@pytest.mark.parametrize("B", [512, 128, 1024])
+def test_full_size_properties_batch512(B):
+    """BASELINE.json full sizes -- configs[1] (B=512), the per-rank shape of configs[2] (b=128 = 1024 / 8) and the metric's own batch
+    (B=1024, one GPU) at L=120, C=35: properties that need no oracle run.
        * recon rows are probability vectors; * the fused loss equals a plain torch evaluation of train.py:31-38 on the same
        recon; * run-to-run bitwise determinism of loss and gradients; * batch-row independence: the first 64 molecules give the
        same mu as a B=64 run."""
     torch.manual_seed(42)
     model = mv.MolecularVAE().to(dev)
     gen = torch.Generator().manual_seed(1234)
-    idx = torch.randint(0, 35, (512, 120), generator=gen).to(dev)
-    eps = (1e-2 * torch.randn(512, 292, generator=gen)).to(dev)
+    idx = torch.randint(0, 35, (B, 120), generator=gen).to(dev)
+    eps = (1e-2 * torch.randn(B, 292, generator=gen)).to(dev)
     ohe = torch.nn.functional.one_hot(idx, 35).float()
 
     def run(ix, ep, oh):
@@ -355,7 +357,7 @@ def test_full_size_properties_batch512():
         return recon.detach(), mu.detach(), logvar.detach(), loss.detach(), gn
 
     recon, mu, logvar, loss, gn = run(idx, eps, ohe)
-    assert torch.allclose(recon.sum(-1), torch.ones(512, 120, device=dev), atol=1e-5) and float(recon.min()) >= 0
+    assert torch.allclose(recon.sum(-1), torch.ones(B, 120, device=dev), atol=1e-5) and float(recon.min()) >= 0
     bce = torch.nn.functional.binary_cross_entropy(recon.reshape(-1), ohe.reshape(-1))
     ref_loss = 120 * bce - 0.5 * torch.mean(1. + mu - logvar ** 2 - torch.exp(mu))
     assert abs(float(loss) - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
