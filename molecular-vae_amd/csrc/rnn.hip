@@ -254,6 +254,142 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
   }
 }
 
+// ---------------------------------------------------------------------------------------------- forward, gate-major tile
+// LSTM / bf16 / whole 64-unit tiles.  The roles of the MFMA operands are swapped with respect to lstm_step_fwd_kernel: the A operand
+// is the WEIGHT tile (64 hidden units x 4 gates = 256 rows of [W_ih | W_hh]), the B operand the batch tile (BNB rows of x_t | h_{t-1}),
+// so the accumulator tile is [gate rows][batch rows] and lane (q = lane >> 4, c = lane & 15) of a wave owns, for batch row c of each
+// 16-row sub-tile, FOUR CONSECUTIVE W rows per fragment (rows 4q .. 4q+3).  The LDS image of the weight tile is filled in a permuted
+// row order (the LDS-DMA source address is per lane, so this costs nothing):
+//     LDS row r = 128 wm + 16 mi + j   <-   W row  g * H + j0 + 32 wm + 8 (j >> 2) + 4 p + (j & 3),   g = mi >> 1, p = mi & 1
+// With it, fragments mi = 2g (p = 0) and 2g + 1 (p = 1) of a lane hold gate g of EIGHT consecutive hidden units 32 wm + 8 q .. + 7 of
+// one batch row -- all four gates of those units sit in the lane's own registers.  The whole cell update (bias, non-linearities,
+// c' = f c + i g, h' = o tanh c') therefore runs in registers: no LDS staging, no barrier, no bank conflicts, and every access of
+// c / h / saved gates is a 16-byte (bf16) or 2 x 16-byte (fp32) vector per lane, 64 contiguous bytes per 4 lanes.
+// 512 threads = 8 waves as 2 (weight rows) x 4 (batch rows), all of them loading AND computing (tile_gemm_pipe8); the 256-row batch
+// tile needs 64 KB of operands per 64-deep K-step for 8.4 MFLOP (128 FLOP/B, against 85 for the 128-row tile), which is what counts for
+// a loop bound by the per-CU L2 -> LDS intake.
+// Small batches (B <= 256) take the same kernel with 32-unit tiles (BMW = 128 weight rows, 256 threads = 4 waves along the batch rows).
+template <int BMW, int BNB, int NBUF, int MODE = 2>
+__global__ __launch_bounds__(BMW * 2) void lstm_step_fwd_gm_kernel(StepArgsF p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(BMW == 256 || BMW == 128, "weight rows per tile: 64 or 32 units x 4 gates");
+  constexpr int NT = BMW * 2;                   // 8 waves as 2 (weight rows) x 4 (batch rows), or 4 waves as 1 x 4
+  constexpr int BU = BMW / 4;                   // hidden units per tile
+  constexpr int MI = 8, NI = BNB / 64;          // wave tile: 128 weight rows x (BNB / 4) batch rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int per_task = p.tiles_m * p.tiles_j;
+  const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task);
+  const int task = bid / per_task;
+  const int rem = bid - task * per_task;
+  const int tj = rem / p.tiles_m, tm = rem - tj * p.tiles_m;   // tiles sharing a weight panel are neighbours on one XCD
+  const StepTaskF& q = p.t[task];
+  const int n0 = tm * BNB, j0 = tj * BU, H = p.H, B = p.B;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int g = 0; g < NI; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#ifdef MVAE_TUNING
+  const bool run_main = !(p.dbg & 2);
+#else
+  constexpr bool run_main = true;
+#endif
+  if (run_main) {
+    PipeSeg<BMW, BNB, NT> s0, s1;
+    auto wrow = [&](int r) -> int {             // LDS row -> W row (permutation above)
+      const int mi = (r >> 4) & 7, j = r & 15;
+      return (mi >> 1) * H + j0 + 32 * (r >> 7) + 8 * (j >> 2) + 4 * (mi & 1) + (j & 3);
+    };
+    {
+      const uint32_t lda = (uint32_t)q.lda0 * 2u, ldw = (uint32_t)q.ldw0 * 2u;
+      auto offW = [&](int r) -> uint32_t { return (uint32_t)wrow(r) * ldw; };
+      auto offX = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < B ? (uint32_t)gn * lda : PIPE_OOB; };
+      pipe_seg_init<T, BMW, BNB, NT>(s0, q.W0, (uint32_t)(4 * H) * ldw, q.A0, (uint32_t)B * lda, offW, offX, q.K0, tid);
+      if (q.A0 == nullptr) s0.nk = 0;
+    }
+    {
+      const uint32_t lda = (uint32_t)q.lda1 * 2u, ldw = (uint32_t)q.ldw1 * 2u;
+      auto offW = [&](int r) -> uint32_t { return (uint32_t)wrow(r) * ldw; };
+      auto offX = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < B ? (uint32_t)gn * lda : PIPE_OOB; };
+      pipe_seg_init<T, BMW, BNB, NT>(s1, q.W1, (uint32_t)(4 * H) * ldw, q.A1, (uint32_t)B * lda, offW, offX, q.K1, tid);
+      if (q.A1 == nullptr) s1.nk = 0;
+    }
+    tile_gemm_pipe_all<T, BMW, BNB, MI, NI, NBUF, NT, MODE>(smem, s0, s1, wm * 128, wn * (16 * NI), acc, tid);
+  }
+#ifdef MVAE_TUNING
+  if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.c_out[0] = 1.f; return; }
+#endif
+
+  // ---- epilogue in registers: lane -> hidden units ub .. ub + 7, batch rows n0 + wn * 16 NI + 16 ni + c
+  const int lq = lane >> 4, lc = lane & 15;
+  const int ub = j0 + 32 * wm + 8 * lq;
+  float bias[4][8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (q.bias) load8<float>(q.bias + g * H + ub, bias[g]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias[g][e] = 0.f;
+    }
+  }
+  T* hout = reinterpret_cast<T*>(q.h_out);
+  T* gout = reinterpret_cast<T*>(q.g_out);
+  T* csave = reinterpret_cast<T*>(q.c_save);
+  auto load_cprev = [&](int ni, float (&v)[8]) {
+    const int row = n0 + wn * (16 * NI) + ni * 16 + lc;
+    if (q.c_prev && row < B) load8<float>(q.c_prev + (long)row * H + ub, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+  };
+  float cp[8], cpn[8];                          // previous cell state of sub-tile ni, and of ni + 1 (requested one sub-tile ahead)
+  load_cprev(0, cp);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = n0 + wn * (16 * NI) + ni * 16 + lc;
+    if (ni + 1 < NI) load_cprev(ni + 1, cpn);
+    if (row >= B) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cp[e] = cpn[e];
+      continue;
+    }
+    float pre[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pre[g][e] = acc[2 * g + (e >> 2)][ni][e & 3] + bias[g][e];
+    if (q.add) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a[8];
+        load8<float>(q.add + (long)row * q.add_ld + g * H + ub, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre[g][e] += a[e];
+      }
+    }
+    float gi[8], gf[8], gg[8], go[8], c[8], h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gi[e] = act_sigmoid<T>(pre[0][e]); gf[e] = act_sigmoid<T>(pre[1][e]); gg[e] = act_tanh<T>(pre[2][e]); go[e] = act_sigmoid<T>(pre[3][e]);
+      c[e] = gf[e] * cp[e] + gi[e] * gg[e];
+      h[e] = go[e] * act_tanh<T>(c[e]);
+    }
+    store8<float>(q.c_out + (long)row * H + ub, c);
+    store8<T>(hout + (long)row * q.ldh + ub, h);
+    if (gout) {
+      T* g4 = gout + (long)row * 4 * H + ub;
+      store8<T>(csave + (long)row * H + ub, c);
+      store8<T>(g4, gi); store8<T>(g4 + H, gf); store8<T>(g4 + 2 * H, gg); store8<T>(g4 + 3 * H, go);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cp[e] = cpn[e];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 struct StepTaskB {
   const void *A0, *A1, *W0, *W1;
@@ -369,10 +505,13 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = wave >> 1, wn = wave & 1;
   const int per_task = p.tiles_m * p.tiles_n;
-  const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task * (p.split ? 2 : 1));
+  const int nsp = p.split ? p.split : 1;         // split mode: 2 = one workgroup per K-segment, 4 = per half K-segment
+  const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task * nsp);
   const int task2 = bid / per_task;
-  const int task = p.split ? (task2 >> 1) : task2;
-  const int seg = task2 & 1;                     // split mode: this workgroup contracts ONE of the two K-segments
+  const int task = task2 / nsp;
+  const int sp = task2 - task * nsp;
+  const int seg = (nsp == 4) ? (sp >> 1) : sp;   // which K-segment this workgroup contracts (split mode)
+  const int half = (nsp == 4) ? (sp & 1) : 0;    // which half of it (4-way split)
   const int rem = bid - task2 * per_task;
   const int tn = rem / p.tiles_m, tm = rem - tn * p.tiles_m;
   const StepTaskB& q = p.t[task];
@@ -398,14 +537,18 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       const uint32_t lda = (uint32_t)q.lda0 * sz, ldw = (uint32_t)q.ldw0 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
-      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)H * ldw, offA, offB, q.K0, tid & 255);
+      const int kh = (nsp == 4) ? q.K0 / 2 : q.K0, ko = half * kh * (int)sz;         // 4-way split: this half's K range (bytes)
+      pipe_seg_init<T, BM, BN>(s0, q.A0 ? reinterpret_cast<const char*>(q.A0) + ko : nullptr, (uint32_t)B * lda - ko,
+                               reinterpret_cast<const char*>(q.W0) + ko, (uint32_t)H * ldw - ko, offA, offB, kh, tid & 255);
       if (p.split && seg == 1) s0.nk = 0;
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
-      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, q.K1, tid & 255);
+      const int kh = (nsp == 4) ? q.K1 / 2 : q.K1, ko = half * kh * (int)sz;
+      pipe_seg_init<T, BM, BN>(s1, q.A1 ? reinterpret_cast<const char*>(q.A1) + ko : nullptr, (uint32_t)B * lda - ko,
+                               reinterpret_cast<const char*>(q.W1) + ko, (uint32_t)H * ldw - ko, offA, offB, kh, tid & 255);
       if (p.split && seg == 0) s1.nk = 0;
     }
     if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
@@ -457,7 +600,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
   const bool vec = p.vec != 0;
   if (p.split) {
     // split mode (host guarantees whole tiles and the vector path): store this segment's fp32 partial tile; lstm_bwd_epi_kernel sums
-    float* part = p.partial + ((long)(task * 2 + seg) * B) * H;
+    float* part = p.partial + ((long)(task * nsp + sp) * B) * H;
 #pragma unroll
     for (int it = 0; it < (BM * GPR + NTHR - 1) / NTHR; ++it) {
       const int lrow = tid / GPR + it * (NTHR / GPR);
@@ -498,13 +641,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_epi_kernel(StepArgsB p) {
   const int row = (int)(rem / gpr), j8 = (int)(rem - (long)row * gpr) * 8;
   const StepTaskB& q = p.t[task];
   float dh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const float* p0 = p.partial + ((long)(task * 2) * B + row) * H + j8;
-  if (q.A0) { float a[8]; load8<float>(p0, a);
+  const int nsp = p.split, per_seg = nsp >> 1;
+  const float* p0 = p.partial + ((long)(task * nsp) * B + row) * H + j8;
+  for (int s = 0; s < nsp; ++s) {                // fixed order: deterministic
+    if ((s / per_seg == 0) ? (q.A0 == nullptr) : (q.A1 == nullptr)) continue;
+    float a[8]; load8<float>(p0 + (long)s * B * H, a);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dh[e] += a[e]; }
-  if (q.A1) { float a[8]; load8<float>(p0 + (long)B * H, a);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dh[e] += a[e]; }
+    for (int e = 0; e < 8; ++e) dh[e] += a[e];
+  }
   bwd_cell_group<T>(p, q, row, j8, 8, true, dh);
 }
 
@@ -593,6 +737,22 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   BJ = tune_int("MVAE_BJ", BJ);
   if (BJ == 64 && (!pipe || dt != MVAE_BF16)) BJ = 32;
   if (BJ == 64) BM = 128;
+  // gate-major tile (lstm_step_fwd_gm_kernel: LSTM, bf16, epilogue in registers): the largest of (64 units x 256 rows), (64 x 128),
+  // (32 x 128), (32 x 64) that still gives about one workgroup per CU.  MVAE_FWD_GM: 0 = never, 1 = choose, 256256 / 256128 / 128128 /
+  // 128064 = force that (weight rows, batch rows) tile (tests).
+  const int gm_knob = tune_int("MVAE_FWD_GM", 1);
+  int BMW = 0, BNB = 0;
+  if (gm_knob && !gru && dt == MVAE_BF16 && pipe && vec && H % 64 == 0) {
+    static const int cand[4][2] = {{256, 256}, {256, 128}, {128, 128}, {128, 64}};
+    for (int c = 0; c < 4 && !BMW; ++c) {
+      const long tiles = (long)((B + cand[c][1] - 1) / cand[c][1]) * (H / (cand[c][0] / 4)) * NL;
+      // measured (4 x 1024, us / launch, this tile vs the 128 x (64 x 4) wave-specialised kernel): B=1024 67 vs 76, B=512 42.7 vs 42.9,
+      // B=256 (32 x 128) 29.4 vs 28.5 -> not chosen, B=128 (32 x 64) 19.5 vs 21.0
+      const bool chosen = gm_knob == 1 && B >= cand[c][1] && tiles >= 192 && c != 2;
+      if (gm_knob == cand[c][0] * 1000 + cand[c][1] || chosen) { BMW = cand[c][0]; BNB = cand[c][1]; }
+    }
+  }
+  if (BMW) { BM = BNB; BJ = BMW / 4; }
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + BJ - 1) / BJ; a.vec = vec ? 1 : 0;
 #ifdef MVAE_TUNING
   a.dbg = tune_int("MVAE_DBG", 0);
@@ -634,6 +794,23 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_j), block(256);
+    if (BMW) {
+      block = dim3(BMW * 2);
+      if (BMW == 256 && BNB == 256) {
+        lds = 2 * (256 + 256) * KB;
+#ifdef MVAE_TUNING
+        const int mode = tune_int("MVAE_GM_MODE", 2);
+        if (mode == 0) { MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<256, 256, 2, 0>)); continue; }
+        if (mode == 1) { MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<256, 256, 2, 1>)); continue; }
+        if (mode == 3) { MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<256, 256, 2, 3>)); continue; }
+#endif
+        MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<256, 256, 2>));
+      }
+      else if (BMW == 256) { lds = 3 * (256 + 128) * KB; MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<256, 128, 3>)); }
+      else if (BNB == 128) { lds = 4 * (128 + 128) * KB; MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<128, 128, 4>)); }
+      else { lds = 4 * (128 + 64) * KB; MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<128, 64, 4>)); }
+      continue;
+    }
 #define FWD_CASE(TT_, BM_, NB_) if (BJ == 32 && BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
     if (BJ == 64 && nbuf == 3) {
       if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3, true>)); }
@@ -658,7 +835,7 @@ size_t rnn_rowres_bwd_workspace(int layers, int T, int B, int H);
 
 size_t rnn_bwd_workspace_bytes(const mvae_rnn_bwd_desc* d) {
   if (!d || d->layers < 1 || d->B < 1 || d->H < 1 || d->T < 1) return 0;
-  const size_t split = (size_t)d->layers * 2 * d->B * d->H * sizeof(float);      // two fp32 partial dh tiles per cell of a wavefront launch
+  const size_t split = (size_t)d->layers * 4 * d->B * d->H * sizeof(float);      // up to four fp32 partial dh tiles per cell of a wavefront launch
   const size_t rowres = rnn_rowres_bwd_workspace(d->layers, d->T, d->B, d->H);   // inter-layer input gradients of the row-resident schedule
   return split > rowres ? split : rowres;
 }
@@ -707,13 +884,24 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   // each CU then streams (64+64) operand rows per 4096 outputs.  Splitting the contraction by SEGMENT across workgroups doubles the
   // parallelism instead: 128 x 128 tiles move half the bytes per output; the fp32 partial tiles (2 x B x H per cell, L2-resident) are summed
   // by a second, fully parallel element-wise launch that also does the gate-derivative math.
-  const int split_knob = tune_int("MVAE_BWD_SPLIT", 1);      // 0 = never, 1 = when it fills the chip, 2 = whenever the shape allows (tests)
-  const bool split = split_knob && dt == MVAE_BF16 && pipe && vec && B % 128 == 0 && H % 128 == 0 && d->split_ws &&
-                     d->split_ws_bytes >= (size_t)NL * 2 * B * H * sizeof(float) &&
-                     (split_knob == 2 || (long)(B / 128) * (H / 128) * 2 * NL >= 256);   // measured: B=512 56.8 vs 60.3 us, B=256 48.5 vs 45.4 us
-  if (split) { BM = 128; BN = 128; }
+  // Tile / split choice (largest tile that still gives about one workgroup per CU): (256 x 128, 2 segments) for B >= 1024 at 4 x 1024,
+  // (128 x 128, 2) at B = 512, (128 x 128, 4 = half segments) at B = 256, (128 x 64, 4) at B = 128.
+  // MVAE_BWD_SPLIT: 0 = never, 1 = choose, 2 = (128 x 128, 2) whenever the shape allows, 2562 / 1284 / 644 = force (tests).
+  const int split_knob = tune_int("MVAE_BWD_SPLIT", 1);
+  int nsplit = 0;
+  if (split_knob && dt == MVAE_BF16 && pipe && vec && B % 128 == 0 && H % 128 == 0 && d->split_ws) {
+    struct Cand { int bm, bn, ns, key; };
+    static const Cand cand[4] = {{256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
+    for (int c = 0; c < 4 && !nsplit; ++c) {
+      if (B % cand[c].bm || (cand[c].ns == 4 && (4 * H) % (2 * ke))) continue;
+      const long wgs = (long)(B / cand[c].bm) * (H / cand[c].bn) * cand[c].ns * NL;
+      if (split_knob == cand[c].key || (split_knob == 1 && wgs >= 192)) { BM = cand[c].bm; BN = cand[c].bn; nsplit = cand[c].ns; }
+    }
+    if (nsplit && d->split_ws_bytes < (size_t)NL * nsplit * B * H * sizeof(float)) nsplit = 0;
+  }
+  const bool split = nsplit != 0;
   StepArgsB a;
-  a.lengths = d->lengths; a.cell = d->cell; a.split = split ? 1 : 0; a.partial = split ? reinterpret_cast<float*>(d->split_ws) : nullptr;
+  a.lengths = d->lengths; a.cell = d->cell; a.split = nsplit; a.partial = split ? reinterpret_cast<float*>(d->split_ws) : nullptr;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
 #ifdef MVAE_TUNING
   a.dbg = tune_int("MVAE_DBG", 0);
@@ -722,7 +910,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
 #endif
   const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
   const bool ws = tune_int("MVAE_WS_BWD", 1) != 0;      // loader / consumer wave specialisation of the split-mode GEMM kernel
-  size_t lds = (size_t)(split ? 4 : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
+  size_t lds = (size_t)(split ? (BM == 256 ? 3 : 4) : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
   const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   bool want_dh0 = false;
@@ -762,9 +950,11 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * ldg, dt)); q.ldg = ldg;
     }
     a.ntask = n;
-    dim3 grid(n * a.tiles_m * a.tiles_n * (split ? 2 : 1)), block(256);
+    dim3 grid(n * a.tiles_m * a.tiles_n * (split ? nsplit : 1)), block(256);
     if (split) {
-      if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true>)); block = dim3(256); }
+      if (BM == 256) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 256, 128, 3, true>)); block = dim3(256); }
+      else if (BN == 64) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true>)); block = dim3(256); }
+      else if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true>)); block = dim3(256); }
       else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4>));
       const long groups = (long)n * B * (H / 8);
       hipLaunchKernelGGL((lstm_bwd_epi_kernel<bf16_t>), dim3((unsigned)((groups + 255) / 256)), block, 0, st, a);

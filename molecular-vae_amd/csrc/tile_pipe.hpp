@@ -7,34 +7,36 @@
 // Requirements (checked on the host): every K extent is a multiple of the K-step (128 bytes), operand
 // buffers are < 2 GiB.
 #pragma once
+#include <type_traits>
 #include "tile.hpp"
 
 constexpr uint32_t PIPE_OOB = 0x80000000u;   // voffset of an invalid row: beyond any num_records we accept
 
-template <int BM, int BN> struct PipeSeg {
+// NT = threads that issue the LDS-DMA pieces of a stage (256: one piece set per wave 0-3; 512: all eight waves of a 512-thread workgroup)
+template <int BM, int BN, int NT = 256> struct PipeSeg {
   __amdgpu_buffer_rsrc_t ra, rb;
-  uint32_t offA[BM * 8 / 256];
-  uint32_t offB[BN * 8 / 256];
+  uint32_t offA[BM * 8 / NT];
+  uint32_t offB[BN * 8 / NT];
   int nk;
 };
 
 // rowoff(r) -> byte offset of tile row r (k = 0) inside the operand buffer, or PIPE_OOB.
-template <typename T, int BM, int BN, typename RowOffA, typename RowOffB>
-__device__ __forceinline__ void pipe_seg_init(PipeSeg<BM, BN>& s, const void* A, uint32_t bytesA, const void* B, uint32_t bytesB,
+template <typename T, int BM, int BN, int NT = 256, typename RowOffA, typename RowOffB>
+__device__ __forceinline__ void pipe_seg_init(PipeSeg<BM, BN, NT>& s, const void* A, uint32_t bytesA, const void* B, uint32_t bytesB,
                                               RowOffA rowoffA, RowOffB rowoffB, int K, int tid) {
   constexpr int KE = KB / (int)sizeof(T);
   s.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A), 0, (int)bytesA, 0x00020000);
   s.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(B), 0, (int)bytesB, 0x00020000);
   s.nk = (A != nullptr) ? K / KE : 0;
 #pragma unroll
-  for (int i = 0; i < BM * 8 / 256; ++i) {
-    const int id = tid + i * 256, row = id >> 3, pos = id & 7;
+  for (int i = 0; i < BM * 8 / NT; ++i) {
+    const int id = tid + i * NT, row = id >> 3, pos = id & 7;
     const uint32_t ro = rowoffA(row);
     s.offA[i] = (ro == PIPE_OOB) ? PIPE_OOB : ro + (uint32_t)(((pos ^ row) & 7) << 4);
   }
 #pragma unroll
-  for (int i = 0; i < BN * 8 / 256; ++i) {
-    const int id = tid + i * 256, row = id >> 3, pos = id & 7;
+  for (int i = 0; i < BN * 8 / NT; ++i) {
+    const int id = tid + i * NT, row = id >> 3, pos = id & 7;
     const uint32_t ro = rowoffB(row);
     s.offB[i] = (ro == PIPE_OOB) ? PIPE_OOB : ro + (uint32_t)(((pos ^ row) & 7) << 4);
   }
@@ -110,22 +112,29 @@ __device__ __forceinline__ void tile_mma_asm(uint32_t a_base, uint32_t b_base, c
       mma16<T>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
 }
 
+__device__ __forceinline__ void ws_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Issue the (BM + BN) * 8 / 256 LDS-direct loads of pipeline stage `st` (K-steps of segment 0 first, then segment 1).
-template <int BM, int BN, int NBUF>
-__device__ __forceinline__ void pipe_issue_stage(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int st, int wave) {
+template <int BM, int BN, int NBUF, int NT = 256>
+__device__ __forceinline__ void pipe_issue_stage(char* smem, const PipeSeg<BM, BN, NT>& s0, const PipeSeg<BM, BN, NT>& s1, int st, int wave) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass cannot type-check LDS address-space casts / gfx950 builtins
   char* stage = smem + (st % NBUF) * ((BM + BN) * KB);
   const bool first = st < s0.nk;
-  const PipeSeg<BM, BN>& s = first ? s0 : s1;
+  const PipeSeg<BM, BN, NT>& s = first ? s0 : s1;
   const uint32_t kbyte = (uint32_t)(first ? st : st - s0.nk) * KB;
 #pragma unroll
-  for (int i = 0; i < BM * 8 / 256; ++i) {
-    lds_void_t* dst = (lds_void_t*)(stage + (i * 256 + wave * 64) * 16);
+  for (int i = 0; i < BM * 8 / NT; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + (i * NT + wave * 64) * 16);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + kbyte, 0, 0, 0);
   }
 #pragma unroll
-  for (int i = 0; i < BN * 8 / 256; ++i) {
-    lds_void_t* dst = (lds_void_t*)(stage + BM * KB + (i * 256 + wave * 64) * 16);
+  for (int i = 0; i < BN * 8 / NT; ++i) {
+    lds_void_t* dst = (lds_void_t*)(stage + BM * KB + (i * NT + wave * 64) * 16);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + kbyte, 0, 0, 0);
   }
 #endif
@@ -166,6 +175,165 @@ __device__ __forceinline__ void tile_gemm_pipe(char* smem, const PipeSeg<BM, BN>
   __builtin_amdgcn_s_barrier();                               // LDS free for the caller (epilogue scratch / next use)
 }
 
+
+// Pieces [LO, HI) of the LPS = (BM + BN) * 8 / NT LDS-DMA pieces a thread issues per stage (A pieces first).
+template <int BM, int BN, int NBUF, int NT, int LO, int HI>
+__device__ __forceinline__ void pipe_issue_part(char* smem, const PipeSeg<BM, BN, NT>& s0, const PipeSeg<BM, BN, NT>& s1, int st, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;
+  char* stage = smem + (st % NBUF) * ((BM + BN) * KB);
+  const bool first = st < s0.nk;
+  const PipeSeg<BM, BN, NT>& s = first ? s0 : s1;
+  const uint32_t kbyte = (uint32_t)(first ? st : st - s0.nk) * KB;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    if (i < LO || i >= HI) continue;
+    lds_void_t* dst = (lds_void_t*)(stage + (i * NT + wave * 64) * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + kbyte, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if (NA + i < LO || NA + i >= HI) continue;
+    lds_void_t* dst = (lds_void_t*)(stage + BM * KB + (i * NT + wave * 64) * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + kbyte, 0, 0, 0);
+  }
+#endif
+}
+
+__device__ __forceinline__ void SB() { __builtin_amdgcn_sched_barrier(0); }     // pins the DMA / MFMA interleave as written
+
+// MFMAs of fragment rows [M0, M1) of one K-half
+template <typename T, int MI, int NI, int M0, int M1>
+__device__ __forceinline__ void mma_rows(const u32x4 (&a)[MI], const u32x4 (&b)[NI], f32x4 (&acc)[MI][NI]) {
+#pragma unroll
+  for (int mi = M0; mi < M1; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      mma16<T>(__builtin_bit_cast(uint4, a[mi]), __builtin_bit_cast(uint4, b[ni]), acc[mi][ni]);
+}
+
+// All-waves form: NT threads (512 = eight waves, two per SIMD; 256 = four waves for small tiles), EVERY wave both issues its share of
+// the LDS-DMA pieces and computes.  For tiles whose accumulators need all eight waves' registers (256 x 256: 128 accumulator VGPRs per
+// wave).  A K-step is four MFMA blocks -- (K-half 0 | 1) x (fragment rows 0..MI/2-1 | MI/2..MI-1) -- and the A fragments of block i+1
+// are read into the second of two MI/2-fragment register sets under the MFMAs of block i (B fragments: one set per K-half), so the
+// fragment registers are 2 x (MI/2 + NI) instead of 2 x (MI + NI): what lets a 128 x 64 wave tile fit 256 VGPRs with room to spare.
+//   barrier(kt) sits between blocks 2 and 3 of K-step kt-1: every wave has waited for its own pieces of stage kt (counted vmcnt) and
+//   holds everything it needs of stage kt-1 in registers -> stage kt is readable, the buffer of stage kt-1 is free and is refilled with
+//   stage kt+NBUF-1.
+// The refill's DMA pieces cost their issuing wave ~100 cycles each, during which it issues no MFMA, and the two waves of a SIMD run
+// this loop in lockstep (same barrier).  So (MODE bit 0) the pieces are spread over the rows of an MFMA block instead of issued as one
+// burst, and (MODE bit 1) they are STAGGERED between the SIMD partners: waves 0..NT/128-1 interleave them with block 3 right behind the
+// barrier, the other half of the waves with block 0 of the NEXT K-step -- while one partner issues DMA the other issues MFMAs.  (The
+// counted vmcnt is the same for both: the deferred pieces are issued before the next wait.)
+// One MFMA block (fragment rows M0 .. M0+GA-1 of one K-half) with the refill of stage `st` issued beside it when `refill` (wave-uniform)
+// is set.  Only the DMA issue sits under the branch, never an MFMA: the accumulators stay in one straight-line live range.
+template <typename T, int BM, int BN, int NBUF, int NT, int MI, int NI, int GA, bool SPREAD, int M0>
+__device__ __forceinline__ void pipe_block_with_refill(char* smem, const PipeSeg<BM, BN, NT>& s0, const PipeSeg<BM, BN, NT>& s1, bool refill, int st,
+                                                       int wave, const u32x4 (&a)[GA], const u32x4 (&b)[NI], f32x4 (&acc)[MI][NI]) {
+  constexpr int LPS = (BM + BN) * 8 / NT;
+  if constexpr (SPREAD && GA == 4 && LPS % 4 == 0) {
+    constexpr int Q = LPS / 4;
+    if (refill) pipe_issue_part<BM, BN, NBUF, NT, 0, Q>(smem, s0, s1, st, wave);
+    SB();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) mma16<T>(__builtin_bit_cast(uint4, a[0]), __builtin_bit_cast(uint4, b[ni]), acc[M0 + 0][ni]);
+    SB();
+    if (refill) pipe_issue_part<BM, BN, NBUF, NT, Q, 2 * Q>(smem, s0, s1, st, wave);
+    SB();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) mma16<T>(__builtin_bit_cast(uint4, a[1]), __builtin_bit_cast(uint4, b[ni]), acc[M0 + 1][ni]);
+    SB();
+    if (refill) pipe_issue_part<BM, BN, NBUF, NT, 2 * Q, 3 * Q>(smem, s0, s1, st, wave);
+    SB();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) mma16<T>(__builtin_bit_cast(uint4, a[2]), __builtin_bit_cast(uint4, b[ni]), acc[M0 + 2][ni]);
+    SB();
+    if (refill) pipe_issue_part<BM, BN, NBUF, NT, 3 * Q, LPS>(smem, s0, s1, st, wave);
+    SB();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) mma16<T>(__builtin_bit_cast(uint4, a[3]), __builtin_bit_cast(uint4, b[ni]), acc[M0 + 3][ni]);
+  } else {
+    if (refill) pipe_issue_stage<BM, BN, NBUF, NT>(smem, s0, s1, st, wave);
+    SB();
+#pragma unroll
+    for (int r = 0; r < GA; ++r)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) mma16<T>(__builtin_bit_cast(uint4, a[r]), __builtin_bit_cast(uint4, b[ni]), acc[M0 + r][ni]);
+  }
+}
+template <typename T, int MI, int NI, int GA, int M0>
+__device__ __forceinline__ void pipe_block(const u32x4 (&a)[GA], const u32x4 (&b)[NI], f32x4 (&acc)[MI][NI]) {
+#pragma unroll
+  for (int r = 0; r < GA; ++r)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) mma16<T>(__builtin_bit_cast(uint4, a[r]), __builtin_bit_cast(uint4, b[ni]), acc[M0 + r][ni]);
+}
+
+template <typename T, int BM, int BN, int MI, int NI, int NBUF, int NT, int MODE = 3>
+__device__ __forceinline__ void tile_gemm_pipe_all(char* smem, const PipeSeg<BM, BN, NT>& s0, const PipeSeg<BM, BN, NT>& s1, int arow0,
+                                                   int brow0, f32x4 (&acc)[MI][NI], int tid) {
+  constexpr int STAGE = (BM + BN) * KB;
+  constexpr int LPS = (BM + BN) * 8 / NT;
+  constexpr int GA = MI / 2;
+  constexpr bool SPREAD = (MODE & 1) != 0, STAGGER = (MODE & 2) != 0 && NT == 512;
+  static_assert(MI % 2 == 0 && NBUF >= 2 && (NBUF - 2) * LPS < 64, "vmcnt range");
+  static_assert(GA + NI <= 15, "lgkmcnt range");
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "whole LDS-DMA pieces per thread");
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool late = STAGGER && wave >= NT / 128;                          // wave-uniform
+  const int nk = s0.nk + s1.nk;
+  if (nk <= 0) return;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const int lr = lane & 15, lk = lane >> 4;
+  uint32_t a_lane[2], b_lane[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    a_lane[kk] = (uint32_t)swz(arow0 + lr, kk * 4 + lk);
+    b_lane[kk] = (uint32_t)swz(brow0 + lr, kk * 4 + lk) + BM * KB;
+  }
+  constexpr uint32_t G1 = GA * 16 * KB;                                   // byte offset of fragment rows GA.. inside the wave's A rows
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s)
+    if (s < nk) pipe_issue_stage<BM, BN, NBUF, NT>(smem, s0, s1, s, wave);
+  u32x4 aX[GA], aY[GA], bh0[NI], bh1[NI];
+  if (NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>(); else wait_vmcnt<0>();
+  ws_barrier();                                                           // barrier(0)
+  int pend = (NBUF - 1 < nk) ? NBUF - 1 : -1;                             // stage whose refill is due (its buffer is free)
+  if (pend >= 0 && !late) { pipe_issue_stage<BM, BN, NBUF, NT>(smem, s0, s1, pend, wave); pend = -1; }
+  FragRead<0, GA, 16 * KB>::run(aX, lds0 + a_lane[0]);
+  FragReadB<0, NI, NI, 0>::run(bh0, lds0 + b_lane[0]);
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
+    FragRead<0, GA, 16 * KB>::run(aY, st + a_lane[0] + G1);              // (h0, rows GA..)
+    FragReadB<0, NI, NI, 0>::run(bh1, st + b_lane[1]);                   // (h1)
+    wait_lgkmcnt<GA + NI>();                                              // aX, bh0 arrived
+    if constexpr (STAGGER) {                                              // block 0 (+ the staggered waves' refill)
+      pipe_block_with_refill<T, BM, BN, NBUF, NT, MI, NI, GA, SPREAD, 0>(smem, s0, s1, late && pend >= 0, pend, wave, aX, bh0, acc);
+      if (late) pend = -1;
+    } else pipe_block<T, MI, NI, GA, 0>(aX, bh0, acc);
+    SB();
+    FragRead<0, GA, 16 * KB>::run(aX, st + a_lane[1]);                   // (h1, rows 0..GA-1)
+    wait_lgkmcnt<NI + GA>();                                              // aY arrived
+    pipe_block<T, MI, NI, GA, GA>(aY, bh0, acc);                          // block 1
+    SB();
+    FragRead<0, GA, 16 * KB>::run(aY, st + a_lane[1] + G1);              // (h1, rows GA..)
+    wait_lgkmcnt<GA>();                                                   // aX, bh1 arrived
+    pipe_block<T, MI, NI, GA, 0>(aX, bh1, acc);                           // block 2
+    wait_lgkmcnt<0>();                                                    // aY arrived: every read of stage kt is done
+    if (kt + 1 < nk) {
+      if (kt + 1 + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>(); else wait_vmcnt<0>();    // my pieces of stage kt+1 have landed
+      ws_barrier();                                                       // barrier(kt + 1): the buffer stage kt used is free
+      pend = (kt + NBUF < nk) ? kt + NBUF : -1;
+      const uint32_t sn = lds0 + (uint32_t)(((kt + 1) % NBUF) * STAGE);
+      FragRead<0, GA, 16 * KB>::run(aX, sn + a_lane[0]);
+      FragReadB<0, NI, NI, 0>::run(bh0, sn + b_lane[0]);
+    }
+    pipe_block_with_refill<T, BM, BN, NBUF, NT, MI, NI, GA, SPREAD, GA>(smem, s0, s1, !late && pend >= 0, pend, wave, aY, bh1, acc);   // block 3
+    if (!late) pend = -1;
+    SB();
+  }
+}
 
 // =====================================================================================================================
 // TN form (bf16): C[m][n] = sum_k A[k][m] * B[k][n] with both operands K-major in memory (row = k, m / n contiguous):
@@ -318,13 +486,6 @@ __device__ __forceinline__ void tile_gemm_pipe_tn(char* smem, const PipeSegTN<MI
 // The consumers are software-pipelined across the barrier: the first half of stage kt+1 is read under the MFMAs of the second
 // half of stage kt, so no fragment-read latency is exposed after the prologue.
 // =====================================================================================================================
-__device__ __forceinline__ void ws_barrier() {
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 template <int NBUF, int MI>
 __device__ __forceinline__ void tile_gemm_ws_tn(char* smem, const PipeSegTN<MI>& s, int wm, int wn, f32x4 (&acc)[MI][4], int tid) {
   constexpr int LPS = MI + 4;

@@ -198,11 +198,24 @@ def test_lstm_tile_variants_vs_oracle(env, monkeypatch):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("split", ["0", "2"])
+@pytest.mark.parametrize("split", ["0", "2", "2562", "1284", "644"])
 def test_lstm_bwd_split_segment_schedule(split, monkeypatch):
-    """Backward with the contraction split by segment across workgroups (128x128 partial tiles + element-wise second launch) vs fused."""
+    """Backward with the contraction split across workgroups -- by K-segment (128x128 or 256x128 partial tiles) or by half segment
+    (4 partial tiles per output: the small-batch schedules) + element-wise second launch -- vs the fused single-launch form."""
     monkeypatch.setenv("MVAE_BWD_SPLIT", split)
     errs = _lstm_case(torch.bfloat16, 5, 256, 128, 3, 8)
+    bad = {k: v for k, v in errs.items() if v > 3e-2}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("gm", ["256256", "256128", "128128", "128064"])
+@pytest.mark.parametrize("shape", [(4, 200, 192, 3), (3, 256, 128, 4), (1, 70, 64, 2)])
+def test_lstm_fwd_gate_major_tiles(gm, shape, monkeypatch):
+    """The gate-major forward tile (weights as the MFMA A operand, permuted LDS rows, cell update in registers) in each of its four
+    (weight rows, batch rows) shapes, forced at oracle-checkable sizes incl. ragged batch tiles and T = 1."""
+    monkeypatch.setenv("MVAE_FWD_GM", gm)
+    T, B, H, NL = shape
+    errs = _lstm_case(torch.bfloat16, T, B, H, NL, 8)
     bad = {k: v for k, v in errs.items() if v > 3e-2}
     assert not bad, bad
 

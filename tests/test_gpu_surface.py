@@ -1,6 +1,7 @@
 """GPU tests (pytest -m gpu) of the surface around the training step: forward-only evaluation (train.py:120-153), accuracy
 (train.py:109-113), optimiser hand-over to / from torch.optim.Adam (train.py:81,173), the stand-alone Lambda head (models.py:80-94)
 and the two-rank data-parallel equivalence of the HIP path (train_distributed.py:72 replaced by per-process DP)."""
+import copy
 import json
 import os
 import subprocess
@@ -103,7 +104,7 @@ def test_fused_adam_hands_over_to_torch_adam_and_back():
         mv.train_step(m1, fa, loss_fn, idx, ohe, eps=eps)
     m2.load_state_dict(m1.state_dict())
     ta = torch.optim.Adam(m2.parameters(), lr=1.0)
-    ta.load_state_dict(fa.state_dict())
+    ta.load_state_dict(copy.deepcopy(fa.state_dict()))     # as a checkpoint file would: torch's loader keeps references to what it is given
 
     def grads(m):
         m.zero_grad(set_to_none=True)
@@ -120,7 +121,8 @@ def test_fused_adam_hands_over_to_torch_adam_and_back():
     torch.manual_seed(7)
     m3 = mv.MolecularVAE(i=24, o=16, c=12, dtype=torch.float32).to(dev)
     fb = mv.FusedAdam(m3.parameters(), lr=1.0, max_grad_norm=3.0)
-    mv.load_checkpoint({"model_state_dict": {"module." + k: v for k, v in m2.state_dict().items()}, "optimizer_state_dict": ta.state_dict()}, m3, fb)
+    mv.load_checkpoint({"model_state_dict": {"module." + k: v for k, v in m2.state_dict().items()},
+                        "optimizer_state_dict": copy.deepcopy(ta.state_dict())}, m3, fb)
     grads(m2)
     torch.nn.utils.clip_grad_norm_(m2.parameters(), 3.0)
     ta.step()
