@@ -63,17 +63,15 @@ for epoch in range(1, args.epochs + 1):
                 recon, _, _ = model(data)
                 acc = mv.exact_match_accuracy(recon, data)                          # train.py:109-113
             print(f"train: {epoch} / {batch_idx}\t{float(loss):.4f}\tacc {float(acc):.3f}", flush=True)
-    with torch.no_grad():                                                           # test(epoch), train.py:120-153
-        vl, vn = torch.zeros((), device=dev), 0
-        for data, ohe in test_ds.batches(args.batch_size, shuffle=False, rank=rank, world=world):
-            recon, mu, logvar = model(data)
-            vl += loss_function(recon, ohe, mu, logvar); vn += 1
-    val = float(vl / max(vn, 1))
-    scheduler.step(val)
+    # test(epoch), train.py:120-153: forward-only (no saved state is written under no_grad), every sequence of the shard (drop_last=False)
+    val, acc = mv.evaluate(model, loss_function, test_ds.batches(args.batch_size, shuffle=False, rank=rank, world=world, drop_last=False))
+    if world > 1:                                        # every rank must take the same ReduceLROnPlateau decision
+        t = torch.tensor([val, acc], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t); val, acc = (t / world).tolist()
+    scheduler.step(val)                                  # train.py:165
     if rank == 0:
-        print(f"epoch {epoch}: train {float(total) / max(n, 1):.5f}  val {val:.5f}  lr {optimizer.param_groups[0]['lr']:.2e}", flush=True)
-        torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(), "epoch": epoch,
-                    "charset": charset, "max_len": max_len, "lr": optimizer.param_groups[0]["lr"], "latent_size": args.latent_size},
-                   f"save_{args.batch_size}_{args.optimizer}_{args.latent_size}.pt")   # train.py:170-177
+        print(f"epoch {epoch}: train {float(total) / max(n, 1):.5f}  val {val:.5f}  acc {acc:.4f}  lr {optimizer.param_groups[0]['lr']:.2e}", flush=True)
+        mv.save_checkpoint(f"save_{args.batch_size}_{args.optimizer}_{args.latent_size}.pt", model, optimizer, epoch, charset, max_len,
+                           latent_size=args.latent_size)                             # train.py:170-177
 if world > 1:
     torch.distributed.destroy_process_group()

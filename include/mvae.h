@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 1
+#define MVAE_ABI_VERSION 2
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -141,7 +141,18 @@ typedef struct {
   float* cstate[MVAE_MAX_LAYERS];
   int zero_padded_k;   /* != 0: rows of hs, h0, w_ih (l>0) and w_hh are allocated AND zero up to the next multiple of 128 bytes
                           past H, so the contraction may run over whole K-steps (enables the LDS-direct main loop for e.g. H = 72) */
+  /* Inter-layer dropout (torch.nn.GRU(dropout=p), train mode; mosesvae.py:73-79): layer l+1 reads  hdrop[l] = hs[l] * keep / (1 - p)
+   * instead of hs[l] (the recurrence of layer l itself still reads hs[l]).  hdrop[l] [T][B][ldh] dtype for l < layers-1, all NULL = no
+   * dropout.  keep(l,t,b,j) comes from drop_mask[l] ([T][B][H] bytes, 1 = keep) when given (parity tests inject the reference's draw),
+   * else from the counter-based hash  mvae_dropout_keep(drop_seed, ((l*T + t)*B + b)*H + j, drop_p)  -- no hidden RNG state. */
+  void* hdrop[MVAE_MAX_LAYERS];
+  const uint8_t* drop_mask[MVAE_MAX_LAYERS];
+  float drop_p; uint32_t drop_seed;
 } mvae_rnn_fwd_desc;
+
+/* keep decision of the device-generated dropout mask (host-callable restatement: the oracle and the tests use the same hash):
+ *   h = idx * 0x9E3779B1 ^ seed; h ^= h >> 16; h *= 0x85EBCA6B; h ^= h >> 13; h *= 0xC2B2AE35; h ^= h >> 16;  keep = h >= (uint32)(p * 2^32) */
+int mvae_dropout_keep(uint32_t seed, uint32_t idx, float p);
 
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
 
@@ -171,6 +182,10 @@ typedef struct {
   float* dh0[MVAE_MAX_LAYERS];                                            /* optional out: gradient w.r.t. h0 (GRU decoder_lat path) */
   void* split_ws; size_t split_ws_bytes;                                  /* optional scratch of mvae_rnn_bwd_workspace(d) bytes: enables the split-K
                                                                              schedules (fp32 partial tiles of dh summed across workgroups) */
+  /* inter-layer dropout of the forward pass (same mask / seed / p): the gradient that layer l receives from layer l+1
+   * (dG^{l+1}_t . W_ih^{l+1}) is multiplied by keep(l,t,b,j) / (1 - p).  drop_p == 0: no dropout. */
+  const uint8_t* drop_mask[MVAE_MAX_LAYERS];
+  float drop_p; uint32_t drop_seed;
 } mvae_rnn_bwd_desc;
 
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream);

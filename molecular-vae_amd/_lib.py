@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # run with any MVAE_* variable set, so a measured number always comes from the product library.
 LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 
+ABI_VERSION = 2
 MVAE_F32, MVAE_BF16 = 0, 1
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
 CELL_LSTM, CELL_GRU = 0, 1
@@ -33,7 +34,8 @@ class RnnFwdDesc(C.Structure):
                 ("cs", _vp * MAX_LAYERS),
                 ("gates", _vp * MAX_LAYERS),
                 ("cstate", _vp * MAX_LAYERS),
-                ("zero_padded_k", _i)]
+                ("zero_padded_k", _i),
+                ("hdrop", _vp * MAX_LAYERS), ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32)]
 
 
 class RnnBwdDesc(C.Structure):
@@ -51,7 +53,8 @@ class RnnBwdDesc(C.Structure):
                 ("dGh", _vp * MAX_LAYERS),
                 ("dstate", _vp * MAX_LAYERS),
                 ("dh0", _vp * MAX_LAYERS),
-                ("split_ws", _vp), ("split_ws_bytes", _sz)]
+                ("split_ws", _vp), ("split_ws_bytes", _sz),
+                ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32)]
 
 
 # name -> (restype, argtypes); mirrors include/mvae.h one to one (tests check every symbol is exported)
@@ -68,6 +71,7 @@ SIGNATURES = {
     "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
+    "mvae_dropout_keep": (_i, [C.c_uint32, C.c_uint32, _f]),
     "mvae_gemm_tn_colsum_supported": (_i, [_i, _i, _i]),
     "mvae_gemm_tn_colsum_workspace": (_sz, [_i, _i, _i]),
     "mvae_gemm_tn_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
@@ -126,7 +130,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.mvae_abi_version() != 1:
+    if lib.mvae_abi_version() != ABI_VERSION:
         raise MvaeError("libmvae_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -50,6 +50,12 @@ int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const v
                                     ws, ws_bytes, (hipStream_t)stream);
 }
 
+int mvae_dropout_keep(uint32_t seed, uint32_t idx, float p) {
+  uint32_t h = idx * 0x9E3779B1u ^ seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h >= (uint32_t)((double)p * 4294967296.0) ? 1 : 0;
+}
+
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) { return rnn_fwd_impl(d, (hipStream_t)stream); }
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d) { return rnn_bwd_workspace_bytes(d); }

@@ -57,6 +57,19 @@ __device__ __forceinline__ int xcd_remap_r(int bid, int n) {   // contiguous til
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---------------------------------------------------------------------------------------------- inter-layer dropout
+// keep / (1 - p) factor of element idx (see mvae_dropout_keep in include/mvae.h): injected byte mask when given, else the hash
+struct DropArgs { float scale; uint32_t thresh, seed; };     // scale = 1 / (1 - p); thresh = (uint32)(p * 2^32)
+__host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t idx) {
+  uint32_t h = idx * 0x9E3779B1u ^ seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ float drop_factor(const DropArgs& da, const uint8_t* mask, uint32_t idx0, long off) {
+  const bool keep = mask ? (mask[off] != 0) : (drop_hash(da.seed, idx0 + (uint32_t)off) >= da.thresh);
+  return keep ? da.scale : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------- forward
 struct StepTaskF {
   const void *A0, *A1, *W0, *W1;
@@ -70,8 +83,11 @@ struct StepTaskF {
   void* g_out;                        // [B,4H] dtype: post-activation gates saved for backward
   const void* hprev_t0;               // GRU, t == 0 only: initial hidden state [B, ld = lda1] dtype (nullptr = zeros)
   int t;                              // time index of this cell (GRU length masking)
+  void* h_drop;                       // [B, ldh] dtype: h * keep / (1 - p) for the layer above (nullptr: no dropout on this cell's output)
+  const uint8_t* dmask;               // [B, H] injected keep mask of this cell (nullptr: hash)
+  uint32_t didx0;                     // hash counter of element (b = 0, j = 0) of this cell
 };
-struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_j, dbg, vec, cell; };
+struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_j, dbg, vec, cell; DropArgs drop; };
 
 // NBUF > 0: LDS-direct ring of that depth; NBUF == 0: generic register-staged loop (any shape)
 // WS: 512 threads, waves 4-7 only load (tile_gemm_ws); everyone takes part in the epilogue
@@ -231,6 +247,12 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
       }
       stn<float>(q.c_out + (long)row * H + j8, c, n, vec);
       stn<T>(hout + (long)row * q.ldh + j8, h, n, vec);
+      if (q.h_drop) {
+        float hd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hd[e] = (e < n) ? h[e] * drop_factor(p.drop, q.dmask, q.didx0, (long)row * H + j8 + e) : 0.f;
+        stn<T>(reinterpret_cast<T*>(q.h_drop) + (long)row * q.ldh + j8, hd, n, vec);
+      }
       if (gout) {           // forward-only passes (no_grad) hand in no save buffers: 12 of the 16 bytes per (row, unit) are not written
         stn<T>(csave + (long)row * H + j8, c, n, vec);
         stn<T>(g4, gi, n, vec); stn<T>(g4 + H, gf, n, vec); stn<T>(g4 + 2 * H, gg, n, vec); stn<T>(g4 + 3 * H, go, n, vec);
@@ -249,6 +271,12 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
       }
       stn<float>(q.c_out + (long)row * H + j8, hs_, n, vec);
       stn<T>(hout + (long)row * q.ldh + j8, hseq, n, vec);
+      if (q.h_drop) {
+        float hd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hd[e] = (e < n) ? hseq[e] * drop_factor(p.drop, q.dmask, q.didx0, (long)row * H + j8 + e) : 0.f;
+        stn<T>(reinterpret_cast<T*>(q.h_drop) + (long)row * q.ldh + j8, hd, n, vec);
+      }
       if (gout) { stn<T>(g4, gr, n, vec); stn<T>(g4 + H, gz, n, vec); stn<T>(g4 + 2 * H, gn, n, vec); stn<T>(g4 + 3 * H, pre[3], n, vec); }
     }
   }
@@ -402,8 +430,11 @@ struct StepTaskB {
   const void* h_prev; long ldhp;      // GRU: h_{t-1} [B, ldhp] dtype (nullptr = zeros)
   float* dh0;                         // GRU pseudo-cell t = -1: gradient w.r.t. the initial hidden state (fp32 [B,H]); gates == nullptr
   int t;
+  int drop;                           // != 0: the segment-1 contraction (gradient from the layer above) is multiplied by keep / (1 - p)
+  const uint8_t* dmask;               // [B, H] injected keep mask of this cell's OUTPUT (nullptr: hash)
+  uint32_t didx0;
 };
-struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split; };
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split; DropArgs drop; };
 
 // Gate-derivative math of one (batch row, 8 hidden units) group, given dh = sum of the two contractions (fp32).
 template <typename T>
@@ -524,6 +555,18 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
 #pragma unroll
     for (int n = 0; n < NI; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const bool fused_drop = q.drop && !p.split && q.A1 != nullptr;      // wave-uniform
+  auto scale_drop = [&]() {                     // accumulator layout: row = 4 (lane >> 4) + r, column = lane & 15 of each 16 x 16 sub-tile
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r, col = n0 + wn * WN + n * 16 + (lane & 15);
+          if (row < B && col < H) acc[i][n][r] *= drop_factor(p.drop, q.dmask, q.didx0, (long)row * H + col);
+        }
+  };
 #ifdef MVAE_TUNING
   const bool run_main = !(p.dbg & 2);
 #else
@@ -551,12 +594,32 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
                                reinterpret_cast<const char*>(q.W1) + ko, (uint32_t)H * ldw - ko, offA, offB, kh, tid & 255);
       if (p.split && seg == 0) s1.nk = 0;
     }
-    if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
-    else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    if (fused_drop) {
+      // inter-layer dropout, fused (single-launch) form: contract the segment that comes from the layer above FIRST, multiply the partial
+      // sums by keep / (1 - p) in the accumulator registers, then add the recurrent segment
+      PipeSeg<BM, BN> se = s0; se.nk = 0;
+      if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s1, se, wm * WM, wn * WN, acc, tid);
+      else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s1, se, wm * WM, wn * WN, acc, tid);
+      scale_drop();
+      if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, se, wm * WM, wn * WN, acc, tid);
+      else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, se, wm * WM, wn * WN, acc, tid);
+    } else {
+      if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+      else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    }
   } else {
     int brow[NI];
 #pragma unroll
     for (int n = 0; n < NI; ++n) brow[n] = wn * WN + n * 16;
+    if (fused_drop && q.A1 != nullptr) {                   // segment from the layer above first, then its dropout factor (see above)
+      const T* A = reinterpret_cast<const T*>(q.A1);
+      const T* W = reinterpret_cast<const T*>(q.W1);
+      const long lda = q.lda1, ldw = q.ldw1;
+      auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
+      auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
+      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+      scale_drop();
+    }
     if (q.A0 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A0);
       const T* W = reinterpret_cast<const T*>(q.W0);
@@ -565,7 +628,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
       tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
     }
-    if (q.A1 != nullptr) {
+    if (!fused_drop && q.A1 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A1);
       const T* W = reinterpret_cast<const T*>(q.W1);
       const long lda = q.lda1, ldw = q.ldw1;
@@ -646,6 +709,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_epi_kernel(StepArgsB p) {
   for (int s = 0; s < nsp; ++s) {                // fixed order: deterministic
     if ((s / per_seg == 0) ? (q.A0 == nullptr) : (q.A1 == nullptr)) continue;
     float a[8]; load8<float>(p0 + (long)s * B * H, a);
+    if (q.drop && s / per_seg == 1) {             // gradient from the layer above: inter-layer dropout factor of this cell's output
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] *= drop_factor(p.drop, q.dmask, q.didx0, (long)row * H + j8 + e);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) dh[e] += a[e];
   }
@@ -697,8 +764,15 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (d->x0 && (!d->w_ih[0] || d->in0 < 1)) return MVAE_ERR_INVALID;
   if (!d->x0 && !d->add0) return MVAE_ERR_INVALID;
   if (d->ldh % epc) return MVAE_ERR_INVALID;
+  // inter-layer dropout: every layer but the last gets a dropped copy of its output, all or none
+  bool drop = false;
+  for (int l = 0; l < NL; ++l) drop = drop || d->hdrop[l] != nullptr;
+  if (drop) {
+    if (!(d->drop_p > 0.f) || d->drop_p >= 1.f) return MVAE_ERR_INVALID;
+    for (int l = 0; l + 1 < NL; ++l) if (!d->hdrop[l]) return MVAE_ERR_INVALID;
+  }
   // narrow f32 stacks (the encoder): row-resident schedule, one launch per layer instead of one per wavefront step
-  if (tune_int("MVAE_ROWRES", 1)) {
+  if (!drop && tune_int("MVAE_ROWRES", 1)) {
     const int rc = rnn_rowres_fwd(d, st);
     if (rc != MVAE_ERR_UNSUPPORTED) return rc;
   }
@@ -742,7 +816,8 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   // 128064 = force that (weight rows, batch rows) tile (tests).
   const int gm_knob = tune_int("MVAE_FWD_GM", 1);
   int BMW = 0, BNB = 0;
-  if (gm_knob && !gru && dt == MVAE_BF16 && pipe && vec && H % 64 == 0) {
+  for (int l = 0; l < NL && drop; ++l) if (d->hdrop[l] && (!al16(d->hdrop[l]))) vec = false;
+  if (gm_knob && !gru && !drop && dt == MVAE_BF16 && pipe && vec && H % 64 == 0) {
     static const int cand[4][2] = {{256, 256}, {256, 128}, {128, 128}, {128, 64}};
     for (int c = 0; c < 4 && !BMW; ++c) {
       const long tiles = (long)((B + cand[c][1] - 1) / cand[c][1]) * (H / (cand[c][0] / 4)) * NL;
@@ -754,6 +829,9 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   }
   if (BMW) { BM = BNB; BJ = BMW / 4; }
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_j = (H + BJ - 1) / BJ; a.vec = vec ? 1 : 0;
+  a.drop.scale = drop ? 1.f / (1.f - d->drop_p) : 1.f;
+  a.drop.thresh = drop ? (uint32_t)((double)d->drop_p * 4294967296.0) : 0u;
+  a.drop.seed = d->drop_seed;
 #ifdef MVAE_TUNING
   a.dbg = tune_int("MVAE_DBG", 0);
 #else
@@ -776,7 +854,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
         q.add = d->add0 ? d->add0 + (long)t * d->add0_tstride : nullptr;
         q.add_ld = 4L * H;
       } else {
-        q.A0 = adv(d->hs[l - 1], (long)t * B * d->ldh, dt);
+        q.A0 = adv(drop ? d->hdrop[l - 1] : d->hs[l - 1], (long)t * B * d->ldh, dt);     // the layer below, after its dropout
         q.lda0 = d->ldh; q.K0 = Hk; q.W0 = d->w_ih[l]; q.ldw0 = d->ldw_ih[l];
         q.add = nullptr; q.add_ld = 0;
       }
@@ -789,6 +867,9 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       q.c_save = (gru || infer) ? nullptr : const_cast<char*>(adv(d->cs[l], (long)t * B * H, dt));
       q.hprev_t0 = (gru && t == 0) ? d->h0[l] : nullptr;
       q.t = t;
+      q.h_drop = (drop && l + 1 < NL) ? const_cast<char*>(adv(d->hdrop[l], (long)t * B * d->ldh, dt)) : nullptr;
+      q.dmask = (drop && d->drop_mask[l]) ? d->drop_mask[l] + ((long)t * B) * H : nullptr;
+      q.didx0 = (uint32_t)((((long)l * T + t) * B) * H);
       q.h_out = const_cast<char*>(adv(d->hs[l], (long)t * B * d->ldh, dt)); q.ldh = d->ldh;
       q.g_out = infer ? nullptr : const_cast<char*>(adv(d->gates[l], (long)t * B * 4 * H, dt));
     }
@@ -858,7 +939,9 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   }
   const long ldg = d->ldg;
   if (ldg < 4L * H || ldg % epc) return MVAE_ERR_INVALID;
-  if (tune_int("MVAE_ROWRES", 1)) {
+  const bool drop = d->drop_p > 0.f;
+  if (drop && d->drop_p >= 1.f) return MVAE_ERR_INVALID;
+  if (!drop && tune_int("MVAE_ROWRES", 1)) {
     const int rc = rnn_rowres_bwd(d, st);
     if (rc != MVAE_ERR_UNSUPPORTED) return rc;
   }
@@ -902,6 +985,9 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   const bool split = nsplit != 0;
   StepArgsB a;
   a.lengths = d->lengths; a.cell = d->cell; a.split = nsplit; a.partial = split ? reinterpret_cast<float*>(d->split_ws) : nullptr;
+  a.drop.scale = drop ? 1.f / (1.f - d->drop_p) : 1.f;
+  a.drop.thresh = drop ? (uint32_t)((double)d->drop_p * 4294967296.0) : 0u;
+  a.drop.seed = d->drop_seed;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
 #ifdef MVAE_TUNING
   a.dbg = tune_int("MVAE_DBG", 0);
@@ -926,7 +1012,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
         q.A1 = nullptr; q.lda1 = ldg; q.K1 = 4 * H; q.W1 = nullptr; q.ldw1 = 0;
         q.dy = nullptr; q.dy_ld = 0; q.gates = nullptr; q.c = nullptr; q.c_prev = nullptr;
         q.dc_in = d->dstate[l]; q.dc_out = nullptr; q.dG = nullptr; q.ldg = ldg; q.h_prev = nullptr; q.ldhp = 0;
-        q.dh0 = d->dh0[l]; q.t = -1;
+        q.dh0 = d->dh0[l]; q.t = -1; q.drop = 0; q.dmask = nullptr; q.didx0 = 0;
       }
       if (n == 0) break;
     }
@@ -946,6 +1032,9 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       q.h_prev = gru ? ((t > 0) ? adv(d->hs[l], (long)(t - 1) * B * d->ldh, dt) : d->h0[l]) : nullptr;
       q.ldhp = (t > 0) ? d->ldh : d->ldh0;
       q.dh0 = nullptr; q.t = t;
+      q.drop = (drop && l < NL - 1) ? 1 : 0;
+      q.dmask = (q.drop && d->drop_mask[l]) ? d->drop_mask[l] + ((long)t * B) * H : nullptr;
+      q.didx0 = (uint32_t)((((long)l * T + t) * B) * H);
       q.dc_out = d->dstate[l] + (long)(t & 1) * B * H;
       q.dG = const_cast<char*>(adv(d->dG[l], (long)t * B * ldg, dt)); q.ldg = ldg;
     }

@@ -6,16 +6,22 @@ The whole forward is one ``torch.autograd.Function`` over the C ABI: embedding f
 (a table gather), wavefront GRU kernels with per-sequence length masking (== pack_sequence / pad_packed_sequence semantics:
 a finished sequence keeps its state and emits zeros), fused heads + reparameterisation + KL, fused token cross-entropy.
 
-Not reproduced this round: the decoder's inter-layer dropout (``d_dropout = 0.2``, train mode only, mosesvae.py:73-79) -- the
-kernels compute the deterministic (eval-mode) network; ``VAE.d_dropout`` is kept for introspection.  ``sample()`` (inference,
-broken upstream: SURVEY section 0) is out of scope.
+Train mode (``model.train()``): the decoder GRU's inter-layer dropout (``d_dropout = 0.2``, mosesvae.py:73-79) runs inside the step
+kernels -- layer l+1 reads ``h^l * keep / (1 - p)`` -- with the keep mask generated on device by a counter-based hash from an explicit
+seed (``forward(..., drop_seed=)``; by default drawn from torch's CPU generator, so ``torch.manual_seed`` makes a run reproducible) or
+injected (``forward(..., drop_mask=)``: uint8 ``[layers-1, T, B, H]``; the parity tests inject the mask the reference drew).  ``eval()``
+computes the deterministic network.  Under data parallelism (an initialised ``torch.distributed`` group) the token mean of the
+reconstruction loss (mosesvae.py:193-197) is taken over the GLOBAL number of non-pad targets (``dp_global_token_mean``), so that the
+all-reduced gradient equals the single-process gradient of the global batch.
 """
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib as L
 from . import ops
 from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD
+from .vocab import PaddedBatch, pad_batch
 
 
 class ReLU(nn.Module):
@@ -58,6 +64,8 @@ class VAE(nn.Module):
         self.decoder = nn.ModuleList([self.decoder_rnn, self.decoder_lat, self.decoder_fc])
         self.vae = nn.ModuleList([self.x_emb, self.encoder, self.decoder])
         self.d_z, self.d_dropout = d_z, d_dropout
+        self.dp_global_token_mean = True     # DP: normalise the CE by the global non-pad token count (see module docstring)
+        self.last_drop_seed = None           # seed of the most recent train-mode forward (None: eval / injected mask)
         self.compute_dtype = dtype
         self._ws = _Workspace()
         self._pack_key, self._packed = None, {}
@@ -77,23 +85,40 @@ class VAE(nn.Module):
     def _plist(self):
         return list(self.parameters())
 
-    def forward(self, x, eps=None):
+    def forward(self, x, eps=None, drop_mask=None, drop_seed=None):
         """x: list of LongTensors (one per sequence, sorted by length descending, as collate() yields them).
-        Returns (kl_loss, recon_loss, z, logvar, x_padded, y) -- mosesvae.py:126-140."""
+        Returns (kl_loss, recon_loss, z, logvar, x_padded, y) -- mosesvae.py:126-140.
+        eps / drop_mask / drop_seed inject the reparameterisation noise and the train-mode inter-layer dropout draw (parity tests)."""
         dev = self.device
-        lengths = [int(t.numel()) for t in x]
-        if any(lengths[i] < lengths[i + 1] for i in range(len(lengths) - 1)):
-            raise RuntimeError("sequences must be sorted by length in decreasing order (pack_sequence, mosesvae.py:151)")
-        B, T = len(x), max(lengths)
-        # one packed host->device transfer instead of one .cuda() per sequence (moses_train_distrib.py:271)
-        x_pad = torch.full((B, T), self.pad, dtype=torch.long)
-        for b, t in enumerate(x):
-            x_pad[b, :lengths[b]] = t.cpu() if t.device.type != "cpu" else t
-        x_pad = x_pad.to(dev, non_blocking=True)
-        len_t = torch.tensor(lengths, dtype=torch.int32).to(dev, non_blocking=True)
+        if isinstance(x, PaddedBatch):                                # already collated into the kernels' layout (vocab.get_padded_collate_fn)
+            x_pad, len_t = x.x_pad.to(dev, non_blocking=True), x.lengths.to(dev, non_blocking=True).to(torch.int32)
+            B, T = x_pad.shape
+        else:
+            # the reference's list of per-sequence tensors: padded where they live (device tensors stay on the device), one transfer
+            b = pad_batch(list(x), self.pad)
+            x_pad, len_t = b.x_pad.to(dev, non_blocking=True), b.lengths.to(dev, non_blocking=True)
+            B, T = x_pad.shape
         if eps is None:
             eps = torch.randn(B, self.d_z, device=dev)              # mosesvae.py:159 randn_like(mu): device generator
-        kl, recon, z, logvar, y = _MosesFn.apply(self, x_pad, len_t, eps.contiguous().float(), *self._plist())
+        NL = self.decoder_rnn.num_layers
+        drop = None
+        if self.training and self.d_dropout > 0 and NL > 1:          # nn.GRU(dropout=d_dropout if d_n_layers > 1 else 0), train mode
+            if drop_mask is not None:
+                m = torch.as_tensor(drop_mask).to(torch.uint8)
+                if tuple(m.shape) != (NL - 1, T, B, self.decoder_rnn.hidden_size):
+                    raise ValueError(f"drop_mask must be [layers-1, T, B, H] = {(NL - 1, T, B, self.decoder_rnn.hidden_size)}, got {tuple(m.shape)}")
+                drop = (float(self.d_dropout), 0, m.contiguous().to(dev))
+                self.last_drop_seed = None
+            else:
+                seed = int(torch.randint(0, 2 ** 31 - 1, (1,))) if drop_seed is None else int(drop_seed)
+                drop = (float(self.d_dropout), seed, None)
+                self.last_drop_seed = seed
+        kl, recon, z, logvar, y, ntok = _MosesFn.apply(self, x_pad, len_t, eps.contiguous().float(), drop, *self._plist())
+        if self.dp_global_token_mean and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # local mean = num_r / cnt_r; the gradient all-reduce averages over ranks, so scale to  num_r * world / sum_r cnt_r
+            tot = ntok.detach().clone()
+            dist.all_reduce(tot)
+            recon = recon * (ntok.detach() * dist.get_world_size() / tot)
         return kl, recon, z, logvar, x_pad, y
 
     def forward_encoder(self, x, eps=None):
@@ -221,7 +246,7 @@ def _kmajor_gemm(ws, tag, A, lda, M, Bm, ldb, N, K, out, dev):
 
 class _MosesFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, x_pad, lengths, eps, *params):
+    def forward(ctx, mod, x_pad, lengths, eps, drop, *params):
         dev = x_pad.device
         _require_cuda(dev, "mosesvae.VAE")
         P = mod._pack(dev)
@@ -265,20 +290,27 @@ class _MosesFn(torch.autograd.Function):
             ops.cast_transpose(h0, B, Hd, dst=hsx_d[l][0])              # h_0 = decoder_lat(z) for every layer (mosesvae.py:185-186)
         gates_d = [W(f"dec_gates{l}", (T, B, 4 * Hd), dt) for l in range(NL)]
         hstate_d = [W(f"dec_hstate{l}", (2, B, Hd)) for l in range(NL)]
+        hd = None
+        if drop is not None:                                            # train mode: dropped copies of the outputs of layers 0 .. NL-2
+            hd = [W(f"dec_hd{l}", (T, B, ldh_d), dt) for l in range(NL - 1)] + [None]
         ops.rnn_fwd(L.CELL_GRU, dt, T, B, Hd, add_d, B * 4 * Hd, pd["Wih"], [pd["ldw"]] * NL, pd["Whh"], [pd["ldw"]] * NL, pd["bias"],
-                    [h[1:] for h in hsx_d], ldh_d, None, gates_d, hstate_d, h0=[h[0] for h in hsx_d], ldh0=ldh_d, lengths=lengths)
+                    [h[1:] for h in hsx_d], ldh_d, None, gates_d, hstate_d, h0=[h[0] for h in hsx_d], ldh0=ldh_d, lengths=lengths,
+                    hdrop=hd, drop_mask=(None if drop is None or drop[2] is None else [drop[2][l] for l in range(NL - 1)]),
+                    drop_p=(drop[0] if drop else 0.0), drop_seed=(drop[1] if drop else 0), tag="moses_dec_fwd")
         TB = T * B
         y_tb = W("y_tb", (TB, V))
         ops.gemm_nt(hsx_d[-1][1:].reshape(TB, ldh_d), P["Wfc"], y_tb, TB, V, Hd, bias=mod.decoder_fc.bias)
         y = torch.empty(B, T, V, device=dev); ops.permute102(y_tb, y, T, B, V)
         loss2 = W("loss2", (2,)); ops.ce_loss_fwd(y_tb, V, x_pad, mod.pad, loss2, B, T, V)
-        ctx.mod, ctx.gen, ctx.x_pad, ctx.lengths, ctx.eps = mod, ws.generation, x_pad, lengths, eps
+        ctx.mod, ctx.gen, ctx.x_pad, ctx.lengths, ctx.eps, ctx.drop = mod, ws.generation, x_pad, lengths, eps, drop
         ctx.set_materialize_grads(False)
-        return kl[0].clone(), loss2[0].clone(), z, lv.clone(), y
+        ntok = loss2[1].clone()
+        ctx.mark_non_differentiable(ntok)
+        return kl[0].clone(), loss2[0].clone(), z, lv.clone(), y, ntok
 
     @staticmethod
-    def backward(ctx, dkl, drecon, dz_ext, dlv_ext, dy_ext):
-        mod, x_pad, lengths, eps = ctx.mod, ctx.x_pad, ctx.lengths, ctx.eps
+    def backward(ctx, dkl, drecon, dz_ext, dlv_ext, dy_ext, _dntok=None):
+        mod, x_pad, lengths, eps, drop = ctx.mod, ctx.x_pad, ctx.lengths, ctx.eps, ctx.drop
         ws = mod._ws
         if ws.generation != ctx.gen:
             raise L.MvaeError("mosesvae.VAE workspace was overwritten by a later forward; run backward before the next forward")
@@ -331,7 +363,10 @@ class _MosesFn(torch.autograd.Function):
         dh0 = [W(f"dec_dh0_{l}", (B, Hd)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_GRU, dt, T, B, Hd, pd["WhhT"], [pd["ldwT"]] * NL, pd["WihT"], [pd["ldwT"]] * NL, dyd, Hd,
                     [h[1:] for h in hsx_d], ldh_d, None, gates_d, dG_d, dstate_d, ldg=ldg_d, h0=[h[0] for h in hsx_d], ldh0=ldh_d,
-                    lengths=lengths, dh0=dh0)
+                    lengths=lengths, dh0=dh0,
+                    drop_mask=(None if drop is None or drop[2] is None else [drop[2][l] for l in range(NL - 1)]),
+                    drop_p=(drop[0] if drop else 0.0), drop_seed=(drop[1] if drop else 0), tag="moses_dec_bwd")
+        hd = [W(f"dec_hd{l}", (T, B, ldh_d), dt) for l in range(NL - 1)] if drop is not None else None
         s4 = W("dec_s4", (4 * Hd,))
         for l in range(NL):
             a = dG_d[l].view(TB, ldg_d)
@@ -339,9 +374,9 @@ class _MosesFn(torch.autograd.Function):
             gw = grads[f"decoder_rnn.weight_hh_l{l}"]
             _kmajor_gemm(ws, "dwhh_rz", a, ldg_d, 2 * Hd, hprev, ldh_d, Hd, TB, gw[:2 * Hd], dev)
             _kmajor_gemm(ws, "dwhh_n", a[:, 3 * Hd:], ldg_d, Hd, hprev, ldh_d, Hd, TB, gw[2 * Hd:], dev)
-            if l > 0:
-                _kmajor_gemm(ws, "dwih", a, ldg_d, 3 * Hd, hsx_d[l - 1][1:].reshape(TB, ldh_d), ldh_d, Hd, TB,
-                             grads[f"decoder_rnn.weight_ih_l{l}"], dev)
+            if l > 0:                                                 # the layer's input: the output of layer l-1 (after its dropout in train mode)
+                xin = hd[l - 1].view(TB, ldh_d) if hd is not None else hsx_d[l - 1][1:].reshape(TB, ldh_d)
+                _kmajor_gemm(ws, "dwih", a, ldg_d, 3 * Hd, xin, ldh_d, Hd, TB, grads[f"decoder_rnn.weight_ih_l{l}"], dev)
             ops.colsum_t(a, TB, 4 * Hd, s4, ldx=ldg_d)
             grads[f"decoder_rnn.bias_ih_l{l}"].copy_(s4[:3 * Hd])
             grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
@@ -404,4 +439,4 @@ class _MosesFn(torch.autograd.Function):
         ops.gemm_nt(etblT, P["ET_p"], grads["encoder_rnn.weight_ih_l0"], 3 * Hq, V, Vp)
         ge = grads["x_emb.weight"]; torch.add(dE, dE2, out=ge)
         ge[mod.pad].zero_()                                           # nn.Embedding(padding_idx=pad): no gradient to the pad row
-        return (None, None, None, None) + tuple(grads[n] for n in names)
+        return (None, None, None, None, None) + tuple(grads[n] for n in names)

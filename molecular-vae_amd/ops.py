@@ -278,8 +278,23 @@ def _fill(arr, tensors):
         arr[i] = t.data_ptr() if t is not None else None
 
 
+def dropout_keep_mask(seed, shape_lt_b_h, p):
+    """Host restatement of the device-generated inter-layer dropout mask (mvae_dropout_keep): uint8 [layers-1... as given][T][B][H], element
+    index = flat position.  Used by the tests / the oracle to draw exactly what the kernels draw."""
+    import numpy as np
+    n = int(np.prod(shape_lt_b_h))
+    idx = np.arange(n, dtype=np.uint64)
+    h = ((idx * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) ^ np.uint64(seed & 0xFFFFFFFF)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    thresh = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    return (h >= thresh).astype(np.uint8).reshape(shape_lt_b_h)
+
+
 def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, cs, gates, cstate,
-            x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, zero_padded_k=False, tag=None):
+            x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, zero_padded_k=False, tag=None,
+            hdrop=None, drop_mask=None, drop_p=0.0, drop_seed=0):
     d = L.RnnFwdDesc()
     NL = len(w_hh)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H, d.in0 = cell, dt_code(dtype), NL, T, B, H, in0
@@ -303,12 +318,18 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
     if cstate is not None:
         _fill(d.cstate, cstate)
     d.zero_padded_k = 1 if zero_padded_k else 0
+    if hdrop is not None:
+        _fill(d.hdrop, hdrop)
+        if drop_mask is not None:
+            _fill(d.drop_mask, drop_mask)
+        d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
     with _Timed(tag):
         check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
 
 
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dstate,
-            ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dh0=None, tag=None):
+            ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dh0=None, tag=None,
+            drop_mask=None, drop_p=0.0, drop_seed=0):
     d = L.RnnBwdDesc()
     NL = len(w_hhT)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
@@ -334,6 +355,10 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     _fill(d.dstate, dstate)
     if dh0 is not None:
         _fill(d.dh0, dh0)
+    if drop_p > 0.0:
+        if drop_mask is not None:
+            _fill(d.drop_mask, drop_mask)
+        d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
     need = L.load().mvae_rnn_bwd_workspace(C.byref(d))     # scratch of the split-K schedules (used only when the shape qualifies)
     sws = Scratch.get(need, dy.device if dy is not None else dG[0].device, tag="rnn_split")
     d.split_ws, d.split_ws_bytes = sws.data_ptr(), need

@@ -68,3 +68,43 @@ def get_collate_fn(vocab):
         data = sorted(data, key=len, reverse=True)
         return [string2tensor(vocab, s) for s in data]
     return collate
+
+
+class PaddedBatch:
+    """A collated batch already in the layout the kernels read: ``x_pad`` int64 [B, T] (pad-filled, rows sorted by length descending)
+    and ``lengths`` int32 [B], both on the target device.  ``mosesvae.VAE.forward`` takes it in place of the list of per-sequence
+    tensors: ONE host->device transfer per batch instead of the reference's one ``.cuda()`` per sequence (moses_train_distrib.py:271)."""
+
+    def __init__(self, x_pad, lengths):
+        self.x_pad, self.lengths = x_pad, lengths
+
+    def __len__(self):
+        return self.x_pad.shape[0]
+
+    def to(self, device, non_blocking=True):
+        return PaddedBatch(self.x_pad.to(device, non_blocking=non_blocking), self.lengths.to(device, non_blocking=non_blocking))
+
+    def tensors(self):
+        """The reference's representation (list of LongTensors) -- for code that still wants it."""
+        return [self.x_pad[b, :int(n)] for b, n in enumerate(self.lengths.tolist())]
+
+
+def pad_batch(tensors, pad):
+    """list of LongTensors sorted by length descending -> PaddedBatch (on the tensors' device)."""
+    lengths = [int(t.numel()) for t in tensors]
+    if any(lengths[i] < lengths[i + 1] for i in range(len(lengths) - 1)):
+        raise RuntimeError("sequences must be sorted by length in decreasing order (pack_sequence, mosesvae.py:151)")
+    x_pad = torch.nn.utils.rnn.pad_sequence(list(tensors), batch_first=True, padding_value=pad)
+    return PaddedBatch(x_pad, torch.tensor(lengths, dtype=torch.int32, device=x_pad.device))
+
+
+def get_padded_collate_fn(vocab, pin_memory=False):
+    """Like ``get_collate_fn`` but returns a PaddedBatch (host tensors, optionally pinned) ready for one asynchronous ``.to(device)``."""
+    inner = get_collate_fn(vocab)
+
+    def collate(data):
+        b = pad_batch(inner(data), vocab.pad)
+        if pin_memory:
+            b = PaddedBatch(b.x_pad.pin_memory(), b.lengths.pin_memory())
+        return b
+    return collate

@@ -20,6 +20,7 @@ ap.add_argument("--compare", nargs=2)
 ap.add_argument("--b", type=int, default=64)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32: re-association noise only (sharp check); bf16: the bench configuration")
+ap.add_argument("--model", default="molvae", choices=["molvae", "moses"])
 args = ap.parse_args()
 if args.compare:
     a, b = (json.load(open(f)) for f in args.compare)
@@ -39,6 +40,37 @@ dev = torch.device("cuda", 0)
 if world > 1:
     import torch.distributed as dist
     dist.init_process_group("gloo")
+if args.model == "moses":
+    # mosesvae.VAE step (moses_train_distrib.py:287-299): variable-length batch, the CE mean runs over the GLOBAL non-pad token count
+    import numpy as np
+    from molecular_vae_amd import mosesvae as MV, vocab as VC
+    v = VC.OneHotVocab([chr(ord("a") + i) for i in range(26)])
+    torch.manual_seed(42)
+    model = MV.VAE(v, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
+    model.d_dropout = 0.0                     # the dropout hash is indexed by batch position, which differs between the two layouts
+    sync = mv.GradSync() if world > 1 else None
+    opt = mv.FusedAdam(model.parameters(), lr=3e-4, max_grad_norm=50.0, grad_sync=sync)
+    rs = np.random.RandomState(9)
+    gb = 2 * args.b
+    lens = rs.randint(6, 40, size=gb)
+    strs = [torch.tensor([v.bos] + rs.randint(0, 26, size=n).tolist() + [v.eos]) for n in lens]
+    eps_all = torch.from_numpy(rs.standard_normal((args.steps, gb, 160)).astype("float32"))
+    mine = list(range(rank, gb, world))       # interleaved shards: different token counts per rank
+    order = sorted(mine, key=lambda i: -len(strs[i]))
+    out = dict(loss=[], psum=[], gnorm=[], world=world)
+    for s_ in range(args.steps):
+        loss, kl, rec = mv.moses_train_step(model, opt, 0.5, [strs[i] for i in order], eps=eps_all[s_, order].to(dev))
+        lt = loss.detach().clone()
+        if world > 1:
+            dist.all_reduce(lt); lt /= world
+        out["loss"].append(float(lt)); out["gnorm"].append(float(opt.last_grad_norm))
+        out["psum"].append(float(sum(p.detach().abs().sum() for p in model.parameters())))
+    out["early_ranges"] = 0
+    if rank == 0 and args.out:
+        json.dump(out, open(args.out, "w")); print(out)
+    if world > 1:
+        dist.destroy_process_group()
+    sys.exit(0)
 L_SEQ, VOCAB, LATENT = 120, 35, 292
 torch.manual_seed(42)
 model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)

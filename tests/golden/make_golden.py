@@ -15,6 +15,7 @@ Fixtures:
   g3_moses.npz   mosesvae.VAE, 30-symbol OneHotVocab, B=6 varlen, dropout off: kl, recon, mu, logvar, y, grads
   g4_traj.npz    5 steps of clip(3.0)+Adam(8e-4) on the g1 model: loss per step, final checksum
   g5_vocab.npz   CharVocab round trips + collate ordering on a fixed SMILES list
+  g6_moses_train.npz  g3's model in train() mode: the inter-layer dropout masks torch drew (reconstructed), kl, recon, y, grads
 """
 import os
 import sys
@@ -186,6 +187,79 @@ def make_g3():
     print("g3 kl", kl.item(), "recon", recon.item(), "params", sorted(seen.keys()))
 
 
+# ------------------------------------------------------------------ G6: mosesvae.VAE in TRAIN mode (decoder_rnn dropout 0.2 active)
+def make_g6():
+    """Same model / weights / sequences as g3, model.train().  torch draws the inter-layer dropout noise inside _VF.gru from the CPU
+    default generator; the same draws are repeated here (manual_seed -> randn_like(mu) -> bernoulli_(0.8) on the packed layer outputs
+    of decoder layers 0 and 1) and unpacked to [layer][T][B][H] keep masks.  The numpy oracle fed with these masks must reproduce the
+    reference's train-mode kl / recon / gradients -- that check runs here (a wrong reconstruction cannot produce a fixture)."""
+    from oracle import np_oracle as O
+    chars = [chr(ord('a') + i) for i in range(26)]
+    v = ref_vocab.OneHotVocab(chars)
+    V = len(v)
+    model = ref_moses.VAE(v).double()
+    params = ip.init_params(ip.moses_shapes(V), 303, 1.5, np.float64)
+    sd = model.state_dict()
+    for k in sd:
+        base = k
+        for pre in ("vae.0.", "vae.1.0.", "encoder.0."):
+            if k.startswith(pre):
+                base = "x_emb." + k[len(pre):]
+        for a, b in (("encoder.1.", "encoder_rnn."), ("encoder.2.", "q_mu."), ("encoder.3.", "q_logvar."),
+                     ("decoder.0.", "decoder_rnn."), ("decoder.1.", "decoder_lat."), ("decoder.2.", "decoder_fc."),
+                     ("vae.1.1.", "encoder_rnn."), ("vae.1.2.", "q_mu."), ("vae.1.3.", "q_logvar."),
+                     ("vae.2.0.", "decoder_rnn."), ("vae.2.1.", "decoder_lat."), ("vae.2.2.", "decoder_fc.")):
+            if k.startswith(a):
+                base = b + k[len(a):]
+        sd[k] = torch.from_numpy(params[base])
+    model.load_state_dict(sd)
+    model.train()                                        # decoder_rnn: dropout=0.2 between its 3 layers (mosesvae.py:73-79)
+    rs = np.random.RandomState(31)
+    lens = sorted(rs.randint(4, 14, size=6).tolist(), reverse=True)
+    strings = ["".join(chars[j] for j in rs.randint(0, 26, size=n)) for n in lens]
+    seqs = [model.string2tensor(s, device="cpu") for s in strings]
+    B, Hd, p_drop = len(seqs), 512, 0.2
+    SEED = 4242
+    torch.manual_seed(SEED)
+    kl, recon, z, logvar, x, y = model(seqs)
+    kl_w = 0.37
+    model.zero_grad()
+    (kl_w * kl + recon).backward()
+    # ---- repeat the generator draws
+    torch.manual_seed(SEED)
+    eps = torch.randn(B, 160, dtype=torch.float64)
+    slens = [len(s) for s in seqs]
+    T = max(slens)
+    n_packed = sum(slens)
+    masks = np.zeros((2, T, B, Hd), np.uint8)
+    for l in range(2):
+        noise = torch.empty(n_packed, Hd, dtype=torch.float64).bernoulli_(1 - p_drop).numpy()
+        r = 0
+        for t in range(T):
+            for b in range(B):
+                if slens[b] > t:
+                    masks[l, t, b] = noise[r]; r += 1
+        assert r == n_packed
+    # ---- the oracle with these masks must land on the reference's numbers
+    res = O.moses_forward(params, [s.numpy() for s in seqs], eps.numpy(), v.pad, drop_masks=masks, drop_p=p_drop)
+    assert abs(res["kl"] - kl.item()) < 1e-10 * abs(kl.item()), (res["kl"], kl.item())
+    assert abs(res["recon"] - recon.item()) < 1e-10 * abs(recon.item()), (res["recon"], recon.item())
+    og = res["grads_for"](kl_w)
+    out = dict(lens=np.array(slens), pad=np.int64(v.pad), V=np.int64(V), eps=eps.numpy(), masks=masks, drop_p=np.float64(p_drop),
+               kl=np.float64(kl.item()), recon=np.float64(recon.item()), y=y.detach().numpy().astype(np.float32), kl_w=np.float64(kl_w))
+    for b, s_ in enumerate(seqs):
+        out[f"seq{b}"] = s_.numpy()
+    worst = 0.0
+    for k, p_ in model.named_parameters():
+        gval = p_.grad.numpy()
+        worst = max(worst, float(np.abs(og[k] - gval).max() / (np.abs(gval).max() + 1e-300)))
+        out["gnorm." + k] = np.float64(np.sqrt((gval ** 2).sum()))
+        out["gslice." + k] = gval.reshape(-1)[:: max(1, gval.size // 64)][:64].copy()
+    assert worst < 1e-9, worst
+    np.savez_compressed(os.path.join(HERE, "g6_moses_train.npz"), **out)
+    print("g6 (train mode) kl", kl.item(), "recon", recon.item(), "keep fraction", masks[:, :, :, :].mean(), "oracle grad err", worst)
+
+
 # ------------------------------------------------------------------ G4
 def make_g4(params, enc, dec, idx):
     g = G1
@@ -241,8 +315,13 @@ def make_g5():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                                # e.g. `make_golden.py g6`: only the named fixtures
+        for name in sys.argv[1:]:
+            globals()["make_" + name]()
+        sys.exit(0)
     params, enc, dec, idx = make_g1()
     make_g4(params, enc, dec, idx)
     make_g2()
     make_g3()
     make_g5()
+    make_g6()

@@ -28,7 +28,7 @@ def t(a, dt=torch.float32):
 
 def test_native_library_is_the_one_running():
     lib = L.load()
-    assert lib.mvae_abi_version() == 1
+    assert lib.mvae_abi_version() == 2
     assert os.path.samefile(L.LIB_PATH, os.path.join(ROOT, "molecular-vae_amd", "libmvae_hip.so"))
     assert any("libmvae_hip.so" in line for line in open("/proc/self/maps"))
 
@@ -467,7 +467,7 @@ def _moses_setup(golden_dir, dtype):
     params = ip.init_params(ip.moses_shapes(V), 303, 1.5, np.float32)
     sd = {k: torch.from_numpy(params[k]) for k in params}
     model.load_state_dict({k: sd[_moses_base(k)] for k in model.state_dict()})
-    return g, model.to(dev), params
+    return g, model.to(dev).eval(), params        # g3 was recorded with model.eval() (dropout off); tests that want train() say so
 
 
 def _moses_base(k):
@@ -518,7 +518,7 @@ def test_moses_larger_batch_vs_oracle():
     params = ip.init_params(ip.moses_shapes(V), 11, 1.0, np.float32)
     model = MV.VAE(v, dtype=torch.bfloat16)
     model.load_state_dict({k: torch.from_numpy(params[_moses_base(k)]) for k in model.state_dict()})
-    model = model.to(dev)
+    model = model.to(dev).eval()
     rs = np.random.RandomState(5)
     lens = sorted(rs.randint(10, 58, size=40).tolist(), reverse=True)
     seqs = [np.concatenate([[v.bos], rs.randint(0, 26, size=n), [v.eos]]).astype(np.int64) for n in lens]
@@ -530,6 +530,72 @@ def test_moses_larger_batch_vs_oracle():
     rg = ref["grads_for"](0.5)
     bad = {k: rel(p_.grad.cpu().numpy(), rg[k]) for k, p_ in model.named_parameters() if rel(p_.grad.cpu().numpy(), rg[k]) > 8e-2}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 2e-5, 5e-4), (torch.bfloat16, 5e-3, 6e-2)])
+def test_g6_moses_train_mode_dropout_vs_reference_fixture(golden_dir, dtype, tl, tg):
+    """mosesvae.VAE in train() mode: the decoder GRU's inter-layer dropout (mosesvae.py:73-79).  The fixture holds the keep masks the
+    REFERENCE drew (reconstructed from its generator, tests/golden/make_golden.py make_g6) with its kl / recon / y / gradients; the HIP
+    path gets the same masks injected and must land on the same numbers; eval() on the same model must give g3's (different) numbers."""
+    g3, model, params = _moses_setup(golden_dir, dtype)
+    g = np.load(os.path.join(golden_dir, "g6_moses_train.npz"))
+    seqs = [torch.from_numpy(g[f"seq{b}"]) for b in range(6)]
+    eps = torch.from_numpy(g["eps"].astype(np.float32)).to(dev)
+    model.train()
+    kl, recon, z, logvar, x, y = model(seqs, eps, drop_mask=g["masks"])
+    assert abs(float(kl) - float(g["kl"])) < tl * abs(float(g["kl"])) and abs(float(recon) - float(g["recon"])) < max(tl, 1e-5) * abs(float(g["recon"]))
+    assert rel(y.detach().cpu().numpy(), g["y"]) < 10 * tl
+    assert abs(float(recon) - float(g3["recon"])) > 1e-3 * abs(float(g3["recon"]))          # dropout really changed the network
+    kl_w = float(g["kl_w"])
+    model.zero_grad(set_to_none=True)
+    (kl_w * kl + recon).backward()
+    torch.cuda.synchronize()
+    for k, p_ in model.named_parameters():
+        gr = p_.grad.double().cpu().numpy()
+        assert abs(np.sqrt((gr ** 2).sum()) - float(g["gnorm." + k])) < 2 * tg * float(g["gnorm." + k]) + 1e-12, k
+        sl = gr.reshape(-1)[:: max(1, gr.size // 64)][:64]
+        assert rel(sl, g["gslice." + k]) < 4 * tg or np.abs(g["gslice." + k]).max() < 1e-12, k
+    model.eval()                                            # same sequences, g3's noise: the deterministic network, g3's numbers
+    kl_e, recon_e, *_ = model(seqs, torch.from_numpy(g3["eps"].astype(np.float32)).to(dev))
+    assert abs(float(recon_e) - float(g3["recon"])) < max(tl, 1e-5) * abs(float(g3["recon"]))
+
+
+@pytest.mark.parametrize("split", ["1", "644"])
+def test_moses_device_generated_dropout_mask_vs_oracle(split, monkeypatch):
+    """Train mode with the mask generated ON DEVICE from an explicit seed (counter-based hash, include/mvae.h mvae_dropout_keep): the
+    oracle, fed with the host restatement of the same hash, must agree -- on the fused backward tiles and on the split-K schedule whose
+    element-wise kernel applies the mask (forced at B = 128); the same seed reproduces the loss bit for bit, another seed does not."""
+    from molecular_vae_amd import mosesvae as MV, vocab as VC
+    monkeypatch.setenv("MVAE_BWD_SPLIT", split)
+    chars = [chr(ord("a") + i) for i in range(26)]
+    v = VC.OneHotVocab(chars)
+    V = len(v)
+    params = ip.init_params(ip.moses_shapes(V), 12, 1.0, np.float32)
+    model = MV.VAE(v, dtype=torch.bfloat16)
+    model.load_state_dict({k: torch.from_numpy(params[_moses_base(k)]) for k in model.state_dict()})
+    model = model.to(dev).train()
+    rs = np.random.RandomState(6)
+    B = 128
+    lens = sorted(rs.randint(8, 30, size=B).tolist(), reverse=True)
+    seqs = [np.concatenate([[v.bos], rs.randint(0, 26, size=n), [v.eos]]).astype(np.int64) for n in lens]
+    eps = rs.standard_normal((B, 160)).astype(np.float32)
+    tseqs = [torch.from_numpy(s) for s in seqs]
+    kl, recon, *_ = model(tseqs, torch.from_numpy(eps).to(dev), drop_seed=20241)
+    assert model.last_drop_seed == 20241
+    (0.5 * kl + recon).backward()
+    T = max(len(s) for s in seqs)
+    masks = ops.dropout_keep_mask(20241, (2, T, B, 512), 0.2)
+    ref = O.moses_forward({k: a.astype(np.float64) for k, a in params.items()}, seqs, eps.astype(np.float64), v.pad, drop_masks=masks, drop_p=0.2)
+    assert abs(float(kl) - ref["kl"]) < 5e-3 * abs(ref["kl"]) and abs(float(recon) - ref["recon"]) < 5e-3 * abs(ref["recon"])
+    rg = ref["grads_for"](0.5)
+    bad = {k: rel(p_.grad.cpu().numpy(), rg[k]) for k, p_ in model.named_parameters() if rel(p_.grad.cpu().numpy(), rg[k]) > 8e-2}
+    assert not bad, bad
+    with torch.no_grad():
+        r_same = float(model(tseqs, torch.from_numpy(eps).to(dev), drop_seed=20241)[1])
+        r_other = float(model(tseqs, torch.from_numpy(eps).to(dev), drop_seed=7)[1])
+        torch.manual_seed(3); r_a = float(model(tseqs, torch.from_numpy(eps).to(dev))[1]); s_a = model.last_drop_seed
+        torch.manual_seed(3); r_b = float(model(tseqs, torch.from_numpy(eps).to(dev))[1])
+    assert r_same == float(recon) and r_other != r_same and r_a == r_b and s_a == model.last_drop_seed
 
 
 def test_moses_sample_greedy_matches_teacher_forced_logits(golden_dir):

@@ -170,6 +170,24 @@ def _run(cmd, timeout=600):
     return r
 
 
+def test_two_rank_moses_data_parallel_uses_the_global_token_mean(tmp_path):
+    """mosesvae.VAE under DP: the reconstruction loss is a mean over non-pad targets (mosesvae.py:193-197); ranks hold different token
+    counts, so each rank rescales its local mean by cnt_r * world / sum cnt (one 4-byte all-reduce).  Two ranks on interleaved shards must
+    then follow the single-process run on the global batch (loss = KL + CE, parameters, clipped-gradient norm) through 3 Adam steps."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = os.path.join(ROOT, "tests", "dp_equiv.py")
+    a, b = os.path.join(str(tmp_path), "m1.json"), os.path.join(str(tmp_path), "m2.json")
+    _run([sys.executable, script, "--model", "moses", "--out", a, "--b", "24", "--steps", "3"])
+    _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+          "--master-port", str(port), script, "--model", "moses", "--out", b, "--b", "24", "--steps", "3"])
+    ra, rb = json.load(open(a)), json.load(open(b))
+    assert rb["world"] == 2
+    for k in ("loss", "psum", "gnorm"):
+        for x, y in zip(ra[k], rb[k]):
+            assert abs(x - y) <= 2e-5 * abs(x), (k, ra[k], rb[k])
+
+
 @pytest.mark.parametrize("dtype", ["f32"])
 def test_two_rank_data_parallel_equals_single_process(tmp_path, dtype):
     """The PRODUCT path under data parallelism: 4 optimiser steps of the full-size model, (a) one process, global batch 2b;

@@ -26,14 +26,19 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mvae.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert lib.mvae_abi_version() == 1
+    assert lib.mvae_abi_version() == 2
     assert lib.mvae_status_string(-2) == b"workspace too small"
 
 
 def test_struct_layout_matches_header():
     # sizes computed by hand from include/mvae.h (LP64): guards the ctypes mirror against drift
-    assert ctypes.sizeof(L.RnnFwdDesc) == 7 * 4 + 4 + 8 * 4 + 8 * (8 * 4) + 8 * 8 + 8 * 8 + 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8
-    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3 + 16
+    assert ctypes.sizeof(L.RnnFwdDesc) == 7 * 4 + 4 + 8 * 4 + 8 * (8 * 4) + 8 * 8 + 8 * 8 + 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + (8 * 8 * 2 + 8)
+    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3 + 16 + (8 * 8 + 8)
+    # the host restatement of the device dropout hash agrees with the library's own (C) restatement
+    lib = L.load()
+    m = ops.dropout_keep_mask(12345, (2, 3, 5, 8), 0.2).reshape(-1)
+    assert [lib.mvae_dropout_keep(12345, i, 0.2) for i in range(m.size)] == m.tolist()
+    assert 0.7 < ops.dropout_keep_mask(7, (1, 50, 40, 64), 0.2).mean() < 0.9
 
 
 def test_state_dict_keys_and_shapes_match_reference_layout():
