@@ -225,6 +225,13 @@ int mvae_conv1d_selu_fwd(int B, int W, int ldx, int64_t x_bs, int Cout, int k, c
  * dw [Cout, Cin, k] and db [Cout] in the reference's parameter layout; dx [B * W, lddx] channels-last (NULL: not needed; else wq required).
  * All pointers 16-byte aligned.  ws: scratch >= mvae_conv1d_selu_bwd_workspace bytes. */
 size_t mvae_conv1d_selu_bwd_workspace(int B, int W, int Cin, int ldx, int Cout, int ldo, int k);
+/* The same pair with the activation as a parameter (MVAE_ACT_NONE / _SELU / _RELU; same workspaces): Conv1d + ReLU of the
+ * models2d.VAE encoder (models2d.py:12-14,24-27). */
+int mvae_conv1d_act_fwd(int act, int B, int W, int ldx, int64_t x_bs, int Cout, int k, const float* x, const float* wp, const float* bias,
+                        float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
+                        const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
+                        void* ws, size_t ws_bytes, void* stream);
 int mvae_conv1d_selu_bwd(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
                          const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                          void* ws, size_t ws_bytes, void* stream);

@@ -88,6 +88,8 @@ SIGNATURES = {
     "mvae_conv1d_selu_fwd": (_i, [_i, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "mvae_conv1d_selu_bwd_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "mvae_conv1d_selu_bwd": (_i, [_i, _i, _i, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "mvae_conv1d_act_fwd": (_i, [_i, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "mvae_conv1d_act_bwd": (_i, [_i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "mvae_selu_bwd": (_i, [_i64, _vp, _vp, _vp]),
     "mvae_lambda_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvae_lambda_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -38,8 +38,11 @@ __global__ __launch_bounds__(256) void conv_unpack_dw_kernel(int Cin, int Cout, 
   }
 }
 
-// dzp [B][Wout + 2(k-1)][ldo]: interior rows = dy * selu'(y) (columns < Cout), everything else zero.
-__global__ __launch_bounds__(256) void conv_dz_pad_kernel(int B, int Wout, int Cout, int ldo, int k, const float* dy, const float* y, float* dzp) {
+// dzp [B][Wout + 2(k-1)][ldo]: interior rows = dy * act'(y) (columns < Cout; derivative expressed through the OUTPUT y), everything else zero.
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  return act == MVAE_ACT_SELU ? selu_grad_from_out(y) : act == MVAE_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : 1.f;
+}
+__global__ __launch_bounds__(256) void conv_dz_pad_kernel(int B, int Wout, int Cout, int ldo, int k, const float* dy, const float* y, float* dzp, int act) {
   const int Wp = Wout + 2 * (k - 1), c4n = ldo / 4;
   const long n = (long)B * Wp * c4n;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -49,10 +52,10 @@ __global__ __launch_bounds__(256) void conv_dz_pad_kernel(int B, int Wout, int C
     if (w >= 0 && w < Wout) {
       const long src = ((long)b * Wout + w) * ldo + c4;
       const float4 g = *reinterpret_cast<const float4*>(dy + src), o = *reinterpret_cast<const float4*>(y + src);
-      if (c4 < Cout) v.x = g.x * selu_grad_from_out(o.x);
-      if (c4 + 1 < Cout) v.y = g.y * selu_grad_from_out(o.y);
-      if (c4 + 2 < Cout) v.z = g.z * selu_grad_from_out(o.z);
-      if (c4 + 3 < Cout) v.w = g.w * selu_grad_from_out(o.w);
+      if (c4 < Cout) v.x = g.x * act_grad_from_out(o.x, act);
+      if (c4 + 1 < Cout) v.y = g.y * act_grad_from_out(o.y, act);
+      if (c4 + 2 < Cout) v.z = g.z * act_grad_from_out(o.z, act);
+      if (c4 + 3 < Cout) v.w = g.w * act_grad_from_out(o.w, act);
     }
     *reinterpret_cast<float4*>(dzp + i * 4) = v;
   }
@@ -72,12 +75,17 @@ size_t mvae_conv1d_selu_fwd_workspace(int B, int W, int ldx, int Cout, int k) {
   return gemm_nt_workspace_bytes(B * (W - k + 1), Cout, k * ldx, MVAE_F32);
 }
 
-int mvae_conv1d_selu_fwd(int B, int W, int ldx, int64_t x_bs, int Cout, int k, const float* x, const float* wp, const float* bias,
-                         float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+int mvae_conv1d_act_fwd(int act, int B, int W, int ldx, int64_t x_bs, int Cout, int k, const float* x, const float* wp, const float* bias,
+                        float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !wp || !y || B < 1 || Cout < 1 || k < 1 || W < k || ldx < 1 || ldy < Cout || x_bs < (int64_t)W * ldx) return MVAE_ERR_INVALID;
+  if (act != MVAE_ACT_NONE && act != MVAE_ACT_SELU && act != MVAE_ACT_RELU) return MVAE_ERR_INVALID;
   const int Wout = W - k + 1;
   return launch_gemm_nt_grouped(MVAE_F32, B * Wout, Cout, k * ldx, x, ldx, Wout, x_bs, (long)B * x_bs, wp, (long)k * ldx, y, ldy, MVAE_F32, bias,
-                                MVAE_ACT_SELU, 0, ws, ws_bytes, (hipStream_t)stream);
+                                act, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+int mvae_conv1d_selu_fwd(int B, int W, int ldx, int64_t x_bs, int Cout, int k, const float* x, const float* wp, const float* bias,
+                         float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+  return mvae_conv1d_act_fwd(MVAE_ACT_SELU, B, W, ldx, x_bs, Cout, k, x, wp, bias, y, ldy, ws, ws_bytes, stream);
 }
 
 static size_t conv_bwd_parts(int B, int W, int Cin, int ldx, int Cout, int ldo, int k, size_t* dwp_bytes, size_t* g_bytes) {
@@ -99,7 +107,13 @@ size_t mvae_conv1d_selu_bwd_workspace(int B, int W, int Cin, int ldx, int Cout, 
 int mvae_conv1d_selu_bwd(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
                          const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                          void* ws, size_t ws_bytes, void* stream) {
+  return mvae_conv1d_act_bwd(MVAE_ACT_SELU, B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, db, dx, lddx, ws, ws_bytes, stream);
+}
+int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
+                        const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
+                        void* ws, size_t ws_bytes, void* stream) {
   if (!dy || !y || !x || !dzp || !dw || !db || !ws) return MVAE_ERR_INVALID;
+  if (act != MVAE_ACT_NONE && act != MVAE_ACT_SELU && act != MVAE_ACT_RELU) return MVAE_ERR_INVALID;
   if (B < 1 || Cin < 1 || Cout < 1 || k < 1 || W < k || ldx < Cin || ldo < Cout || (ldx & 3) || (ldo & 3) || (x_bs & 3) ||
       x_bs < (int64_t)W * ldx) return MVAE_ERR_INVALID;
   if (dx && (!wq || lddx < Cin)) return MVAE_ERR_INVALID;
@@ -112,7 +126,7 @@ int mvae_conv1d_selu_bwd(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout,
   float* dwp = reinterpret_cast<float*>(wsp); wsp += (dwp_bytes + 255) & ~(size_t)255;
   void* gws = wsp; const size_t gws_bytes = ws_bytes - (size_t)(wsp - reinterpret_cast<char*>(ws));
   int rc;
-  hipLaunchKernelGGL(conv_dz_pad_kernel, dim3(cgrid((long)B * Wp * (ldo / 4))), dim3(256), 0, st, B, Wout, Cout, ldo, k, dy, y, dzp);
+  hipLaunchKernelGGL(conv_dz_pad_kernel, dim3(cgrid((long)B * Wp * (ldo / 4))), dim3(256), 0, st, B, Wout, Cout, ldo, k, dy, y, dzp, act);
   MVAE_CHECK_HIP(hipGetLastError());
   if ((rc = launch_colsum(B * Wp, Cout, dzp, ldo, db, gws, gws_bytes, st))) return rc;         // pad rows are zero
   // dwp[o][kc] = sum over output positions of dz[(b,w)][o] * window(b,w)[kc]

@@ -225,21 +225,21 @@ def conv1d_pack_weights(w, Cin, Cout, k, ldx, wp, ldo=0, wq=None):
     check(L.load().mvae_conv1d_pack_weights(Cin, Cout, k, ptr(w), ldx, ptr(wp), ldo, ptr(wq), stream_ptr()), "mvae_conv1d_pack_weights")
 
 
-def conv1d_selu_fwd(x, B, W, ldx, x_bs, Cout, k, wp, bias, y, ldy):
-    """Channels-last sliding-window conv: x[b, w, c] at b*x_bs + w*ldx + c (pad channels zero) -> y[(b*Wout + w), o] (ldy)."""
+def conv1d_selu_fwd(x, B, W, ldx, x_bs, Cout, k, wp, bias, y, ldy, act=L.ACT_SELU):
+    """Channels-last sliding-window conv + bias + activation: x[b, w, c] at b*x_bs + w*ldx + c (pad channels zero) -> y[(b*Wout + w), o] (ldy)."""
     lib = L.load()
     need = lib.mvae_conv1d_selu_fwd_workspace(B, W, ldx, Cout, k)
     ws = Scratch.get(need, x.device) if need else None
-    check(lib.mvae_conv1d_selu_fwd(B, W, ldx, x_bs, Cout, k, ptr(x), ptr(wp), ptr(bias), ptr(y), ldy, ptr(ws), need, stream_ptr()),
-          "mvae_conv1d_selu_fwd")
+    check(lib.mvae_conv1d_act_fwd(act, B, W, ldx, x_bs, Cout, k, ptr(x), ptr(wp), ptr(bias), ptr(y), ldy, ptr(ws), need, stream_ptr()),
+          "mvae_conv1d_act_fwd")
 
 
-def conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, db, dx, lddx):
+def conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, db, dx, lddx, act=L.ACT_SELU):
     lib = L.load()
     need = lib.mvae_conv1d_selu_bwd_workspace(B, W, Cin, ldx, Cout, ldo, k)
     ws = Scratch.get(need, dy.device)
-    check(lib.mvae_conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, ptr(dy), ptr(y), ptr(x), ptr(wq), ptr(dzp), ptr(dw), ptr(db),
-                                   ptr(dx), lddx, ptr(ws), need, stream_ptr()), "mvae_conv1d_selu_bwd")
+    check(lib.mvae_conv1d_act_bwd(act, B, W, Cin, ldx, x_bs, Cout, ldo, k, ptr(dy), ptr(y), ptr(x), ptr(wq), ptr(dzp), ptr(dw), ptr(db),
+                                  ptr(dx), lddx, ptr(ws), need, stream_ptr()), "mvae_conv1d_act_bwd")
 
 
 def lambda_fwd(mulv, eps, z, mu, logvar, B, o):

@@ -51,6 +51,18 @@ def moses_shapes(V, q_h=256, d_z=160, d_h=512, n_dec=3):
     return s
 
 
+def models2d_shapes(H=501, C=35, L=120):
+    """models2d.VAE state_dict (models2d.py:12-21)."""
+    s = {"conv1d1.weight": (9, L, 9), "conv1d1.bias": (9,), "conv1d2.weight": (9, 9, 9), "conv1d2.bias": (9,),
+         "conv1d3.weight": (10, 9, 11), "conv1d3.bias": (10,), "fc0.weight": (435, 90), "fc0.bias": (435,),
+         "fc11.weight": (2, 435), "fc11.bias": (2,), "fc12.weight": (2, 435), "fc12.bias": (2,), "fc2.weight": (2, 2), "fc2.bias": (2,)}
+    for l in range(3):
+        s[f"gru.weight_ih_l{l}"] = (3 * H, 2 if l == 0 else H); s[f"gru.weight_hh_l{l}"] = (3 * H, H)
+        s[f"gru.bias_ih_l{l}"] = (3 * H,); s[f"gru.bias_hh_l{l}"] = (3 * H,)
+    s["fc3.weight"] = (C, H); s["fc3.bias"] = (C,)
+    return s
+
+
 def init_params(shapes, seed, gain=1.0, dtype=np.float32):
     """uniform(-a, a), a = gain / sqrt(fan_in) (biases: a = gain * 0.1); one independent
     stream per key (seed mixed with crc32 of the key) so subsets reproduce."""

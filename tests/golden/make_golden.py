@@ -15,6 +15,7 @@ Fixtures:
   g3_moses.npz   mosesvae.VAE, 30-symbol OneHotVocab, B=6 varlen, dropout off: kl, recon, mu, logvar, y, grads
   g4_traj.npz    5 steps of clip(3.0)+Adam(8e-4) on the g1 model: loss per step, final checksum
   g5_vocab.npz   CharVocab round trips + collate ordering on a fixed SMILES list
+  g7_models2d.npz     models2d.VAE (conv+ReLU encoder, GRU(2->501,3) decoder over the one-hot block), B=3, train + eval mode
   g6_moses_train.npz  g3's model in train() mode: the inter-layer dropout masks torch drew (reconstructed), kl, recon, y, grads
 """
 import os
@@ -260,6 +261,43 @@ def make_g6():
     print("g6 (train mode) kl", kl.item(), "recon", recon.item(), "keep fraction", masks[:, :, :, :].mean(), "oracle grad err", worst)
 
 
+# ------------------------------------------------------------------ G7: models2d.VAE (conv + ReLU encoder, GRU over the one-hot block)
+def make_g7():
+    """models2d.py:8-52 imported as it lies (it has no loss of its own: train.py:31-38's loss_function on its outputs).  B=3, train
+    mode with the recorded randn_like draw, and eval mode (z = mu)."""
+    import models2d as ref_m2d                          # noqa: E402  (reference, read-only)
+    from oracle import np_oracle as O
+    params = ip.init_params(ip.models2d_shapes(), 404, 2.0, np.float64)
+    model = ref_m2d.VAE().double()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    idx = ip.seeded_indices(404, 3, 120, 35)
+    x = torch.nn.functional.one_hot(torch.from_numpy(idx), 35).double()
+    model.train()
+    torch.manual_seed(31337)
+    eps = torch.randn(3, 2, dtype=torch.float64).numpy()       # models2d.py:34 randn_like(std): the first draw of the forward
+    torch.manual_seed(31337)
+    recon, mu, logvar = model(x)
+    loss = ref_loss_function(recon, x, mu, logvar, 120)
+    model.zero_grad(); loss.backward()
+    out = dict(idx=idx, eps=eps, mu=mu.detach().numpy(), logvar=logvar.detach().numpy(), recon=recon.detach().numpy().astype(np.float32),
+               loss=np.float64(loss.item()))
+    ref = O.models2d_loss_and_grads(params, x.numpy(), eps, 120, train=True)
+    assert abs(ref["loss"] - loss.item()) < 1e-10 * abs(loss.item()), (ref["loss"], loss.item())
+    worst = 0.0
+    for k, p_ in model.named_parameters():
+        gval = p_.grad.numpy()
+        worst = max(worst, float(np.abs(ref["grads"][k] - gval).max() / (np.abs(gval).max() + 1e-300)))
+        out["gnorm." + k] = np.float64(np.sqrt((gval ** 2).sum()))
+        out["gslice." + k] = gval.reshape(-1)[:: max(1, gval.size // 64)][:64].copy()
+    assert worst < 1e-8, worst
+    model.eval()
+    r2, mu2, lv2 = model(x)
+    out["eval_loss"] = np.float64(ref_loss_function(r2, x, mu2, lv2, 120).item())
+    out["eval_recon_rows"] = r2.detach().numpy()[:, ::17, :].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "g7_models2d.npz"), **out)
+    print("g7 loss", loss.item(), "eval loss", float(out["eval_loss"]), "oracle grad err", worst)
+
+
 # ------------------------------------------------------------------ G4
 def make_g4(params, enc, dec, idx):
     g = G1
@@ -325,3 +363,4 @@ if __name__ == "__main__":
     make_g3()
     make_g5()
     make_g6()
+    make_g7()

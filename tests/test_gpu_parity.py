@@ -624,3 +624,70 @@ def test_moses_sample_greedy_matches_teacher_forced_logits(golden_dir):
                 assert int(logits[i].argmax()) == int(ids[i + 1]), (b, i)
                 checked += 1
     assert checked >= 20
+
+
+# ---------------------------------------------------------------------------------------------- models2d.VAE (models2d.py)
+@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-5, 5e-4), (torch.bfloat16, 2e-3, 6e-2)])
+def test_g7_models2d_conv_relu_gru_vae(golden_dir, dtype, tl, tg):
+    """The conv(ReLU) + GRU(2 -> 501, 3 layers)-over-the-one-hot-block variant against the fixture recorded from the imported reference
+    models2d.py (train mode with its randn draw injected; eval mode z = mu) and against the oracle: loss, mu / logvar, recon, every gradient.
+    The hidden size runs padded 501 -> 512 inside the kernels; gradients come back in the reference's [1503, 501] layout."""
+    from molecular_vae_amd import models2d as M2
+    g = np.load(os.path.join(golden_dir, "g7_models2d.npz"))
+    params = ip.init_params(ip.models2d_shapes(), 404, 2.0, np.float32)
+    model = M2.VAE(dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to(dev).train()
+    x = torch.nn.functional.one_hot(torch.from_numpy(g["idx"]), 35).float().to(dev)
+    eps = torch.from_numpy(g["eps"].astype(np.float32)).to(dev)
+    recon, mu, logvar = model(x, eps)
+    loss = mv.bce_kl_loss(recon, x, mu, logvar, 120)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(g["loss"])) < tl * abs(float(g["loss"]))
+    assert rel(mu.detach().cpu().numpy(), g["mu"]) < 1e-5 and rel(logvar.detach().cpu().numpy(), g["logvar"]) < 1e-5      # the encoder is f32 in both modes
+    assert rel(recon.detach().cpu().numpy(), g["recon"]) < 20 * tl
+    assert torch.allclose(recon.sum(-1), torch.ones(3, 120, device=dev), atol=1e-5)
+    ref = O.models2d_loss_and_grads({k: v.astype(np.float64) for k, v in params.items()}, O.one_hot(g["idx"], 35), g["eps"], 120)
+    bad = {}
+    for k, p_ in model.named_parameters():
+        gr = p_.grad.double().cpu().numpy()
+        e = rel(gr, ref["grads"][k])
+        if e > tg:
+            bad[k] = e
+        assert abs(np.sqrt((gr ** 2).sum()) - float(g["gnorm." + k])) < 2 * tg * float(g["gnorm." + k]) + 1e-12, k     # reference fixture
+    assert not bad, bad
+    model.eval()
+    with torch.no_grad():
+        r2, mu2, lv2 = model(x)
+        l2 = mv.bce_kl_loss(r2, x, mu2, lv2, 120)
+        rz = model.decode(mu2)
+    assert abs(float(l2) - float(g["eval_loss"])) < tl * abs(float(g["eval_loss"]))
+    assert rel(r2.cpu().numpy()[:, ::17, :], g["eval_recon_rows"]) < 20 * tl and torch.equal(rz, r2)
+    m_e, lv_e = model.encode(x)
+    assert torch.equal(m_e, mu2) and torch.equal(lv_e, lv2)
+
+
+def test_models2d_full_batch_training_steps():
+    """B = 1024 (BASELINE's batch) through FusedAdam: finite, deterministic run to run, loss decreases over a few steps."""
+    from molecular_vae_amd import models2d as M2
+    out = []
+    for rep in range(2):
+        torch.manual_seed(42)
+        model = M2.VAE().to(dev)
+        opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0)
+        loss_fn = mv.make_loss_function(120)
+        gen = torch.Generator().manual_seed(1)
+        idx = torch.randint(0, 35, (1024, 120), generator=gen).to(dev)
+        x = torch.nn.functional.one_hot(idx, 35).float()
+        eps = torch.randn(1024, 2, generator=gen).to(dev)
+        ls = []
+        for _ in range(4):
+            opt.zero_grad(set_to_none=True)
+            recon, mu, lv = model(x, eps)
+            loss = loss_fn(recon, x, mu, lv)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss.detach()))
+        out.append(ls)
+    assert out[0] == out[1] and all(np.isfinite(out[0])) and out[0][-1] < out[0][0]

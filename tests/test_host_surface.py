@@ -64,6 +64,26 @@ def test_mosesvae_state_dict_aliases_match_reference_fixture(golden_dir):
         mv.mosesvae.VAE(type("Bad", (), dict(bos=0, eos=1, pad=2, unk=3, vectors=torch.eye(30)[:, :7], __len__=lambda s: 30))())
 
 
+def test_models2d_module_surface_matches_reference_layout():
+    from oracle import initparams as ip
+    m = mv.models2d.VAE()
+    shapes = ip.models2d_shapes()                                # models2d.py:12-21
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys()) or set(sd.keys()) == set(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    # same RNG consumption as stock torch.nn modules constructed in the reference's order
+    torch.manual_seed(9); a = mv.models2d.VAE().state_dict()
+    torch.manual_seed(9)
+    c1 = torch.nn.Conv1d(120, 9, 9); torch.nn.Conv1d(9, 9, 9); torch.nn.Conv1d(9, 10, 11); torch.nn.Linear(90, 435)
+    torch.nn.Linear(435, 2); torch.nn.Linear(435, 2); torch.nn.Linear(2, 2); gru = torch.nn.GRU(2, 501, 3, batch_first=True); f3 = torch.nn.Linear(501, 35)
+    assert torch.equal(a["conv1d1.weight"], c1.weight) and torch.equal(a["gru.weight_hh_l2"], gru.weight_hh_l2) and torch.equal(a["fc3.bias"], f3.bias)
+    with pytest.raises(L.MvaeError):
+        m(torch.zeros(2, 120, 35))                               # no CPU fallback
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 35, 120))
+
+
 # ------------------------------------------------------------------------------------------------ schedules
 def test_kl_annealer_and_cosine_restart_follow_the_reference_formulas():
     k = mv.KLAnnealer(100)                                      # moses_train_distrib.py:47-58

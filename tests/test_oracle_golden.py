@@ -103,3 +103,21 @@ def test_torch_port_matches_golden(golden_dir):
     loss.backward()
     for k, p in m.named_parameters():
         assert rel(p.grad.numpy(), g["grad." + k]) < 2e-6, k
+
+
+def test_models2d_oracle_matches_reference_fixture(golden_dir):
+    """models2d.VAE (models2d.py:8-52) + train.py:31-38 loss: the numpy restatement against the fixture recorded from the imported reference
+    (train mode with its recorded randn draw; eval mode z = mu)."""
+    g = np.load(os.path.join(golden_dir, "g7_models2d.npz"))
+    p = ip.init_params(ip.models2d_shapes(), 404, 2.0, np.float64)
+    x = O.one_hot(g["idx"], 35)
+    r = O.models2d_loss_and_grads(p, x, g["eps"], 120, train=True)
+    assert abs(r["loss"] - float(g["loss"])) < 1e-10 * abs(float(g["loss"]))
+    assert np.abs(r["mu"] - g["mu"]).max() < 1e-12 and np.abs(r["logvar"] - g["logvar"]).max() < 1e-12
+    assert np.abs(r["recon"] - g["recon"]).max() < 1e-6            # fixture stores recon in f32
+    for k, gr in r["grads"].items():
+        assert abs(np.sqrt((gr ** 2).sum()) - float(g["gnorm." + k])) < 1e-8 * float(g["gnorm." + k]) + 1e-300, k
+        assert np.abs(gr.reshape(-1)[:: max(1, gr.size // 64)][:64] - g["gslice." + k]).max() < 1e-8 * (np.abs(g["gslice." + k]).max() + 1e-300) + 1e-18, k
+    e = O.models2d_loss_and_grads(p, x, g["eps"], 120, train=False)
+    assert abs(e["loss"] - float(g["eval_loss"])) < 1e-10 * abs(float(g["eval_loss"]))
+    assert np.abs(e["recon"][:, ::17, :] - g["eval_recon_rows"]).max() < 1e-6
