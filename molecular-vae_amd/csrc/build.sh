@@ -22,10 +22,13 @@ fi
 pids=()
 for f in gemm rnn rnn_rowres elementwise conv capi; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hpp -nt build/$f.o ] || [ tile.hpp -nt build/$f.o ] || [ tile_pipe.hpp -nt build/$f.o ] || [ kernels.hpp -nt build/$f.o ] || [ ../../include/mvae.h -nt build/$f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    # -Rpass-analysis: per-kernel VGPR / scratch / spill figures go to build/$f.usage.txt (tests assert that no kernel uses scratch)
+    $HIPCC $FLAGS -Rpass-analysis=kernel-resource-usage -c $f.hip -o build/$f.o 2> build/$f.usage.txt &
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+rc=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait $p || rc=1; }; done
+if [ $rc -ne 0 ]; then grep -h -B2 -A6 "error" build/*.usage.txt | head -60; exit 1; fi
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmvae_hip.so build/gemm.o build/rnn.o build/rnn_rowres.o build/elementwise.o build/conv.o build/capi.o
 echo "built $(cd .. && pwd)/libmvae_hip.so"

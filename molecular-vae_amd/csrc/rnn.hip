@@ -527,7 +527,9 @@ __device__ __forceinline__ void bwd_cell_group(const StepArgsB& p, const StepTas
   }
 }
 
-template <typename T, int BM, int BN, int NBUF, bool WS = false>
+// DROP: instantiations that can apply the inter-layer dropout factor inside the fused (single-launch) form -- a separate template
+// flag so that the hot instantiations carry no trace of it (with both forms in one body hipcc moved the LDS-DMA descriptors to scratch).
+template <typename T, int BM, int BN, int NBUF, bool WS = false, bool DROP = false>
 __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB p) {
   constexpr bool PIPE = NBUF > 0;
   constexpr int NTHR = WS ? 512 : 256;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
 #pragma unroll
     for (int n = 0; n < NI; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bool fused_drop = q.drop && !p.split && q.A1 != nullptr;      // wave-uniform
+  const bool fused_drop = DROP && q.drop && !p.split && q.A1 != nullptr;      // wave-uniform; compiled out unless DROP
   auto scale_drop = [&]() {                     // accumulator layout: row = 4 (lane >> 4) + r, column = lane & 15 of each 16 x 16 sub-tile
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -594,15 +596,16 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
                                reinterpret_cast<const char*>(q.W1) + ko, (uint32_t)H * ldw - ko, offA, offB, kh, tid & 255);
       if (p.split && seg == 0) s1.nk = 0;
     }
-    if (fused_drop) {
-      // inter-layer dropout, fused (single-launch) form: contract the segment that comes from the layer above FIRST, multiply the partial
-      // sums by keep / (1 - p) in the accumulator registers, then add the recurrent segment
-      PipeSeg<BM, BN> se = s0; se.nk = 0;
-      if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s1, se, wm * WM, wn * WN, acc, tid);
-      else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s1, se, wm * WM, wn * WN, acc, tid);
-      scale_drop();
-      if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, se, wm * WM, wn * WN, acc, tid);
-      else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, se, wm * WM, wn * WN, acc, tid);
+    if constexpr (DROP) {
+      // inter-layer dropout, fused (single-launch) form: contract the segment that comes from the layer above FIRST (alone), multiply the
+      // partial sums by keep / (1 - p) in the accumulator registers, then add the recurrent segment.  Straight-line: a cell without
+      // dropout (top layer) runs the same two passes with a factor of one.
+      const int nk0 = s0.nk;
+      s0.nk = 0;
+      tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+      if (fused_drop) scale_drop();
+      s0.nk = nk0; s1.nk = 0;
+      tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
     } else {
       if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
       else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
@@ -823,7 +826,8 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       const long tiles = (long)((B + cand[c][1] - 1) / cand[c][1]) * (H / (cand[c][0] / 4)) * NL;
       // measured (4 x 1024, us / launch, this tile vs the 128 x (64 x 4) wave-specialised kernel): B=1024 67 vs 76, B=512 42.7 vs 42.9,
       // B=256 (32 x 128) 29.4 vs 28.5 -> not chosen, B=128 (32 x 64) 19.5 vs 21.0
-      const bool chosen = gm_knob == 1 && B >= cand[c][1] && tiles >= 192 && c != 2;
+      // in situ (whole training step, tests/ab_step.py): B=1024 -- this tile; B=512 (64 x 128) 18.66 vs 18.54 ms / step -> not chosen
+      const bool chosen = gm_knob == 1 && B >= cand[c][1] && tiles >= 192 && c != 2 && c != 1;
       if (gm_knob == cand[c][0] * 1000 + cand[c][1] || chosen) { BMW = cand[c][0]; BNB = cand[c][1]; }
     }
   }
@@ -949,7 +953,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   // stack is small (MFMA-f32 bound per workgroup).  MVAE_BM overrides.
   int BM = 64, BN = 64;
   if (dt == MVAE_F32 && (long)((B + 63) / 64) * ((H + 63) / 64) * NL < 256) { BM = 32; BN = 32; }
-  BM = tune_int("MVAE_BM", BM);
+  if (!drop) BM = tune_int("MVAE_BM", BM);
   if (BM == 32 && dt == MVAE_BF16) BM = 64;
   if (BM != 32) BN = 64;
   const int sz = (dt == MVAE_BF16) ? 2 : 4, ke = KB / sz;
@@ -974,14 +978,20 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   int nsplit = 0;
   if (split_knob && dt == MVAE_BF16 && pipe && vec && B % 128 == 0 && H % 128 == 0 && d->split_ws) {
     struct Cand { int bm, bn, ns, key; };
-    static const Cand cand[4] = {{256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
-    for (int c = 0; c < 4 && !nsplit; ++c) {
+    // (128 x 128, 1) = unsplit, gate-derivative epilogue fused into the wave-specialised GEMM kernel: no partial tiles at all; wins once it
+    // fills the chip by itself (B = 1024: 31.7 vs 32.4 ms / step in situ against (256 x 128, 2); at B = 512 it has 128 workgroups: 70 vs 49 us)
+    static const Cand cand[5] = {{128, 128, 1, 1281}, {256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
+    for (int c = 0; c < 5 && !nsplit; ++c) {
       if (B % cand[c].bm || (cand[c].ns == 4 && (4 * H) % (2 * ke))) continue;
       const long wgs = (long)(B / cand[c].bm) * (H / cand[c].bn) * cand[c].ns * NL;
-      if (split_knob == cand[c].key || (split_knob == 1 && wgs >= 192)) { BM = cand[c].bm; BN = cand[c].bn; nsplit = cand[c].ns; }
+      if (split_knob == cand[c].key || (split_knob == 1 && wgs >= (cand[c].ns == 1 ? 256 : 192))) { BM = cand[c].bm; BN = cand[c].bn; nsplit = cand[c].ns; }
     }
-    if (nsplit && d->split_ws_bytes < (size_t)NL * nsplit * B * H * sizeof(float)) nsplit = 0;
+    // small stacks (GRU 3 x 512 at B = 128: 96 workgroups of (128 x 64, 4)) still beat the fused 64 x 64 tiles: 15 vs 25 us / launch
+    if (!nsplit && split_knob == 1 && (4 * H) % (2 * ke) == 0 && (long)(B / 128) * (H / 64) * 4 * NL >= 64) { BM = 128; BN = 64; nsplit = 4; }
+    if (nsplit > 1 && d->split_ws_bytes < (size_t)NL * nsplit * B * H * sizeof(float)) nsplit = 0;
   }
+  const bool big_fused = nsplit == 1;            // (128 x 128, unsplit): the wave-specialised kernel with the gate-derivative epilogue fused
+  if (big_fused) nsplit = 0;
   const bool split = nsplit != 0;
   StepArgsB a;
   a.lengths = d->lengths; a.cell = d->cell; a.split = nsplit; a.partial = split ? reinterpret_cast<float*>(d->split_ws) : nullptr;
@@ -994,9 +1004,9 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
 #else
   a.dbg = 0;
 #endif
-  const int nbuf = pipe ? tune_int("MVAE_NBUF_BWD", 4) : 0;
+  const int nbuf = pipe ? (drop ? 4 : tune_int("MVAE_NBUF_BWD", 4)) : 0;
   const bool ws = tune_int("MVAE_WS_BWD", 1) != 0;      // loader / consumer wave specialisation of the split-mode GEMM kernel
-  size_t lds = (size_t)(split ? (BM == 256 ? 3 : 4) : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
+  size_t lds = (size_t)(split ? (BM == 256 ? 3 : 4) : big_fused ? 4 : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
   const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   bool want_dh0 = false;
@@ -1040,6 +1050,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n * (split ? nsplit : 1)), block(256);
+    if (big_fused) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true>)); continue; }
     if (split) {
       if (BM == 256) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 256, 128, 3, true>)); block = dim3(256); }
       else if (BN == 64) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true>)); block = dim3(256); }
@@ -1049,6 +1060,13 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       hipLaunchKernelGGL((lstm_bwd_epi_kernel<bf16_t>), dim3((unsigned)((groups + 255) / 256)), block, 0, st, a);
       continue;
     }
+#define BWD_DROP(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<TT_, BM_, (BM_ == 32 ? 32 : 64), NB_, false, true>)); continue; }
+    if (drop) {                                   // fused form with the dropout factor (tile knobs are ignored: see the host choice above)
+      if (dt == MVAE_BF16) { BWD_DROP(bf16_t, 64, 4) BWD_DROP(bf16_t, 64, 0) }
+      else { BWD_DROP(float, 64, 4) BWD_DROP(float, 64, 0) BWD_DROP(float, 32, 4) BWD_DROP(float, 32, 0) }
+      return MVAE_ERR_UNSUPPORTED;
+    }
+#undef BWD_DROP
 #define BWD_CASE(TT_, BM_, NB_) if (BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<TT_, BM_, (BM_ == 32 ? 32 : 64), NB_>)); continue; }
     if (dt == MVAE_BF16) {
       BWD_CASE(bf16_t, 128, 0) BWD_CASE(bf16_t, 128, 3) BWD_CASE(bf16_t, 128, 4) BWD_CASE(bf16_t, 128, 5) BWD_CASE(bf16_t, 128, 6)

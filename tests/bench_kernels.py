@@ -13,7 +13,8 @@ from molecular_vae_amd import ops, _lib as L   # noqa: E402
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 which = sys.argv[3] if len(sys.argv) > 3 else "fwd,bwd,gemm"
-H, NL, PAD = 1024, 4, int(os.environ.get("LDPAD", 64))
+H, NL, PAD = int(os.environ.get("BK_H", 1024)), int(os.environ.get("BK_NL", 4)), int(os.environ.get("LDPAD", 64))
+CELL = L.CELL_GRU if os.environ.get("BK_CELL", "lstm") == "gru" else L.CELL_LSTM
 dev = torch.device("cuda")
 dt = torch.bfloat16
 G4 = 4 * H
@@ -37,11 +38,11 @@ dy = rnd(T * B, H)
 
 
 def fwd():
-    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, 0, Wih, [ldw] * NL, Whh, [ldw] * NL, bias, hs, ldh, cs, gates, cstate)
+    ops.rnn_fwd(CELL, dt, T, B, H, gx0, 0, Wih, [ldw] * NL, Whh, [ldw] * NL, bias, hs, ldh, None if CELL == L.CELL_GRU else cs, gates, cstate)
 
 
 def bwd():
-    ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, WhhT, [ldwT] * NL, WihT, [ldwT] * NL, dy, H, hs, ldh, cs, gates, dG, dstate, ldg=ldg)
+    ops.rnn_bwd(CELL, dt, T, B, H, WhhT, [ldwT] * NL, WihT, [ldwT] * NL, dy, H, hs, ldh, None if CELL == L.CELL_GRU else cs, gates, dG, dstate, ldg=ldg)
 
 
 dW = torch.zeros(G4, H, device=dev)

@@ -111,3 +111,26 @@ def test_shard_helpers():
         seen += list(iter(s))
         assert len(s) == 25
     assert len(set(seen)) == 100
+
+
+def test_no_kernel_spills_to_scratch():
+    """hipcc's per-kernel resource remarks (csrc/build.sh keeps them under csrc/build/): a kernel that spills or keeps an array in scratch
+    runs several times slower without failing any numerical test (it happened: LDS-DMA descriptors selected at run time)."""
+    import glob
+    files = glob.glob(os.path.join(ROOT, "molecular-vae_amd", "csrc", "build", "*.usage.txt"))
+    if not files:
+        pytest.skip("no build remarks here (library built elsewhere)")
+    kernels, bad = 0, []
+    for f in files:
+        name = None
+        for line in open(f, errors="replace"):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1); kernels += 1
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and int(m.group(1)) > 0:
+                bad.append((name, int(m.group(1))))
+            m = re.search(r"VGPRs Spill: (\d+)", line)
+            if m and int(m.group(1)) > 0:
+                bad.append((name, "spill", int(m.group(1))))
+    assert kernels > 50 and not bad, bad
