@@ -98,6 +98,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch; when given the per-GPU work is fixed instead (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="molvae", choices=["molvae", "moses", "models2d"])
+    ap.add_argument("--seq-len", type=int, default=L_SEQ, help="molvae: sequence length (BASELINE configs[4]: 256)")
+    ap.add_argument("--vocab", type=int, default=VOCAB, help="molvae: vocabulary size (BASELINE configs[4]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the B=512 / b=128 / f32 secondary measurements (N = 1)")
     ap.add_argument("--cpu-steps", type=int, default=16)
@@ -126,27 +128,43 @@ def spawn_ranks(args):
 class MolVaeWorkload:
     name = "MolecularVAE(i=120,o=292,c=35) ELBO train step: fwd+loss+bwd+clip(3.0)+Adam(8e-4), synthetic one-hot SMILES [B,120,35]"
 
-    def __init__(self, B, dtype, dev, rank, sync):
+    def __init__(self, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB):
         import torch
         import molecular_vae_amd as mv
-        self.mv, self.B = mv, B
+        self.mv, self.B, self.L, self.C = mv, B, L, C
+        if (L, C) != (L_SEQ, VOCAB):
+            self.name = self.name.replace("i=120,o=292,c=35", f"i={L},o=292,c={C}").replace("[B,120,35]", f"[B,{L},{C}]")
         torch.manual_seed(42)                                     # train.py:73
-        self.model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev)
+        self.model = mv.MolecularVAE(i=L, o=LATENT, c=C, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev)
         self.optimizer = mv.FusedAdam(self.model.parameters(), lr=0.0008, max_grad_norm=3.0, grad_sync=sync)   # train.py:81,102
-        self.loss_function = mv.make_loss_function(L_SEQ)
+        self.loss_function = mv.make_loss_function(L)
+        self.n_params = sum(p.numel() for p in self.model.parameters())
         g = torch.Generator().manual_seed(1234 + rank)
-        self.data = torch.randint(0, VOCAB, (B, L_SEQ), generator=g).to(dev)
-        self.ohe = torch.nn.functional.one_hot(self.data, VOCAB).float()    # the (idx, ohe) pair MoleLoader yields, resident in HBM
+        self.data = torch.randint(0, C, (B, L), generator=g).to(dev)
+        self.ohe = torch.nn.functional.one_hot(self.data, C).float()    # the (idx, ohe) pair MoleLoader yields, resident in HBM
         self.model.encoder.lmbd.draw_eps = lambda b, o, d: 1e-2 * torch.randn(b, o, device=d)   # device noise: no H2D copy in the step
 
     def step(self):
         return self.mv.train_step(self.model, self.optimizer, self.loss_function, self.data, self.ohe)
 
     def flops_per_step(self):
-        return flops_per_molecule() * self.B
+        return flops_per_molecule(self.L, self.C) * self.B
+
+    def hbm_kernels(self, tag_ms):
+        """HBM-bound kernels of the step: algorithmic bytes = one read + one write of their operands; achieved GB/s from
+        the HIP-event time of the launches (BASELINE configs[4] asks for these against the 8 TB/s roof)."""
+        n, m, P = self.B * self.L * self.C, self.B * LATENT, self.n_params
+        algo = {"hbm_bce_kl_loss_fwd": 4 * (2 * n + 2 * m), "hbm_bce_kl_loss_bwd": 4 * (3 * n + 4 * m), "hbm_softmax_fwd": 4 * 2 * n,
+                "hbm_softmax_bwd": 4 * 2 * n + 2 * n, "hbm_sumsq_clip_adam": 4 * P + 7 * 4 * P}
+        out = {}
+        for k, b in algo.items():
+            if k in tag_ms and tag_ms[k] > 0:
+                gbs = b / (tag_ms[k] * 1e-3) / 1e9
+                out[k[4:]] = dict(bytes=b, us=round(1e3 * tag_ms[k], 1), achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 4))
+        return out
 
     def roofline(self, tag_ms, dtype):
-        fwd_f, bwd_f, n_launch = lstm_step_flops(self.B, L_SEQ)
+        fwd_f, bwd_f, n_launch = lstm_step_flops(self.B, self.L)
         fwd_us = 1e3 * tag_ms.get("dec_lstm_fwd", float("nan")) / n_launch
         bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
         peak = BF16_DENSE_PEAK_TFLOPS if dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
@@ -158,10 +176,10 @@ class MolVaeWorkload:
                     traffic=pmc_traffic("lstm_step_fwd", self.B, dtype),
                     launches_per_pass=n_launch, avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
                     flops_per_launch=dict(lstm_step_fwd=fwd_f, lstm_step_bwd=bwd_f), bwd_pair_tflops=round(ach_bwd, 2),
-                    bwd_pair_frac=round(ach_bwd / peak, 4))
+                    bwd_pair_frac=round(ach_bwd / peak, 4), hbm_bound_kernels=self.hbm_kernels(tag_ms))
 
     def config(self, world):
-        return dict(workload=self.name, per_gpu_batch=self.B, global_batch=self.B * world, seq_len=L_SEQ, vocab=VOCAB, latent=LATENT,
+        return dict(workload=self.name, per_gpu_batch=self.B, global_batch=self.B * world, seq_len=self.L, vocab=self.C, latent=LATENT,
                     parallelism=f"dp{world}")
 
 
@@ -182,9 +200,9 @@ def pmc_traffic(kernel_key, B, dtype):
     return None
 
 
-def make_workload(model, B, dtype, dev, rank, sync):
+def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB):
     if model == "molvae":
-        return MolVaeWorkload(B, dtype, dev, rank, sync)
+        return MolVaeWorkload(B, dtype, dev, rank, sync, L, C)
     if model == "moses":
         from bench_extra import MosesWorkload
         return MosesWorkload(B, dtype, dev, rank, sync)
@@ -192,12 +210,12 @@ def make_workload(model, B, dtype, dev, rank, sync):
     return Models2dWorkload(B, dtype, dev, rank, sync)
 
 
-def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label):
+def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_SEQ, C=VOCAB):
     """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
     import torch
     import torch.distributed as dist
     from molecular_vae_amd import ops
-    wl = make_workload(model, B, dtype, dev, rank, sync)
+    wl = make_workload(model, B, dtype, dev, rank, sync, L, C)
     log(f"[{label}] model built, per-GPU batch {B}, dtype {dtype}, world {world}")
     for i in range(warmup):
         loss = wl.step()
@@ -274,7 +292,7 @@ def main():
             die(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
         B, scaling = args.global_batch // world, "strong"
 
-    main_res = measure(args.model, B, args.dtype, args.steps, args.warmup, dev, rank, world, sync, "main")
+    main_res = measure(args.model, B, args.dtype, args.steps, args.warmup, dev, rank, world, sync, "main", args.seq_len, args.vocab)
     metric = {"molvae": "molecules/s (ELBO fwd+bwd+step)", "moses": "molecules/s (mosesvae.VAE KL+CE fwd+bwd+step)",
               "models2d": "molecules/s (models2d.VAE ELBO fwd+bwd+step)"}[args.model]
     cfg = main_res["config"]; cfg["final_loss"] = main_res["final_loss"]
@@ -282,7 +300,8 @@ def main():
                ms_per_step=main_res["ms_per_step"], higher_is_better=True, scaling=scaling, vs_baseline=None, dtype=args.dtype,
                data="synthetic", config=cfg, roofline=main_res["roofline"])
 
-    if world == 1 and args.model == "molvae" and not args.no_secondary and args.batch == 0 and args.dtype == "bf16":
+    if (world == 1 and args.model == "molvae" and not args.no_secondary and args.batch == 0 and args.dtype == "bf16"
+            and (args.seq_len, args.vocab) == (L_SEQ, VOCAB)):
         sec = {}
         for label, b, dt_, st, wu in (("configs1_B512_bf16", 512, "bf16", 10, 3), ("configs2_per_rank_b128_bf16", 128, "bf16", 20, 5),
                                       ("parity_mode_B1024_f32", args.global_batch, "f32", 3, 1)):

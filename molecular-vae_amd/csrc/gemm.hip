@@ -384,7 +384,23 @@ int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, con
   if (c_dtype != MVAE_F32 && c_dtype != MVAE_BF16) return MVAE_ERR_INVALID;
   if (accumulate && c_dtype != MVAE_F32) return MVAE_ERR_INVALID;
   if ((lda % 8) || (ldb % 8) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15)) return MVAE_ERR_INVALID;
-  if ((long)K * lda * 2 >= (1L << 31) || (long)K * ldb * 2 >= (1L << 31)) return MVAE_ERR_UNSUPPORTED;
+  if ((long)K * lda * 2 >= (1L << 31) || (long)K * ldb * 2 >= (1L << 31)) {
+    // operands beyond the 2 GiB a buffer descriptor addresses (BASELINE configs[4]: K = T * B = 524288 rows): equal K-chunks, each a
+    // launch of its own that accumulates onto C (and onto the column sums)
+    const long ldm = lda > ldb ? lda : ldb;
+    const long kmax = (((1L << 31) - 1) / (2 * ldm)) / 4096 * 4096;
+    if (kmax < 4096 || bias || act != MVAE_ACT_NONE || c_dtype != MVAE_F32) return MVAE_ERR_UNSUPPORTED;
+    const long nch = (K + kmax - 1) / kmax;
+    const long kc = ((K + nch - 1) / nch + 63) / 64 * 64;
+    for (long k0 = 0; k0 < K; k0 += kc) {
+      const int kk = (int)(K - k0 < kc ? K - k0 : kc);
+      const int rc = launch_gemm_tn_bf16_colsum(M, N, kk, reinterpret_cast<const char*>(A) + k0 * lda * 2, lda, reinterpret_cast<const char*>(B) + k0 * ldb * 2, ldb,
+                                                C, ldc, c_dtype, nullptr, MVAE_ACT_NONE, (k0 > 0) ? 1 : accumulate, colsum_out, (k0 > 0) ? 1 : colsum_acc,
+                                                ws, ws_bytes, st);
+      if (rc != MVAE_OK) return rc;
+    }
+    return MVAE_OK;
+  }
   Plan pl = make_plan_tn(M, N, K);
   GemmArgs p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.partial = nullptr;

@@ -16,7 +16,8 @@ class _BceKlLossFn(torch.autograd.Function):
         recon_c, target_c = recon.contiguous().float(), target.contiguous().float()
         mu_c, logvar_c = mu.contiguous().float(), logvar.contiguous().float()
         out = torch.empty(3, dtype=torch.float32, device=recon.device)
-        ops.bce_kl_loss_fwd(recon_c, target_c, mu_c, logvar_c, max_len, out)
+        with ops._Timed("hbm_bce_kl_loss_fwd"):
+            ops.bce_kl_loss_fwd(recon_c, target_c, mu_c, logvar_c, max_len, out)
         ctx.save_for_backward(recon_c, target_c, mu_c, logvar_c)
         ctx.max_len = max_len
         ctx.parts = out
@@ -27,7 +28,8 @@ class _BceKlLossFn(torch.autograd.Function):
         recon, target, mu, logvar = ctx.saved_tensors
         drecon = torch.empty_like(recon); dmu = torch.empty_like(mu); dlogvar = torch.empty_like(logvar)
         g = grad_out.contiguous().float().reshape(1)
-        ops.bce_kl_loss_bwd(recon, target, mu, logvar, ctx.max_len, g, drecon, dmu, dlogvar)
+        with ops._Timed("hbm_bce_kl_loss_bwd"):
+            ops.bce_kl_loss_bwd(recon, target, mu, logvar, ctx.max_len, g, drecon, dmu, dlogvar)
         return drecon, None, dmu, dlogvar, None
 
 

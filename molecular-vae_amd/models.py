@@ -573,7 +573,8 @@ class _DecoderFn(torch.autograd.Function):
         logits = ws.get("logits", (TB, Cv), f32, dev)
         ops.gemm_nt(hs[-1].view(TB, ldh), P["Wout"], logits, TB, Cv, H, bias=om.bias)
         recon = torch.empty(B, Lq, Cv, dtype=f32, device=dev)
-        ops.softmax_tb_fwd(logits, Cv, recon, B, Lq, Cv)
+        with ops._Timed("hbm_softmax_fwd"):
+            ops.softmax_tb_fwd(logits, Cv, recon, B, Lq, Cv)
         ctx.mod, ctx.gen, ctx.z = mod, (-1 if infer else ws.generation), z     # a forward-only pass saved nothing: backward refuses
         ctx.from_peer = bool(mod.__dict__.get("_z_from_peer", False))
         ctx.save_for_backward(recon)
@@ -618,7 +619,8 @@ class _DecoderFn(torch.autograd.Function):
         if dt != torch.bfloat16:
             ldT = _pad(TB, 8) + 8
             dlT = W("dlT", (Cv, ldT), dt)
-        ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
+        with ops._Timed("hbm_softmax_bwd"):
+            ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
         dy = W("dy", (TB, H))
         ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
         # K7 backward

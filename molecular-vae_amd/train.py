@@ -207,9 +207,10 @@ class FusedAdam(torch.optim.Optimizer):
                 raise L.MvaeError("FusedAdam implements plain Adam (train.py:81): weight_decay / amsgrad / maximize are not supported")
             if f["p"].device.type != "cuda":
                 raise L.MvaeError("FusedAdam.step runs on the MI355X only (no CPU fallback)")
-            ops.sumsq(f["g"], f["partial"])
-            ops.clip_adam(f["p"], f["g"], f["m"], f["v"], f["partial"], scale, group["max_grad_norm"], group["lr"], b1, b2,
-                          group["eps"], f["step"], f["norm"])
+            with ops._Timed("hbm_sumsq_clip_adam"):
+                ops.sumsq(f["g"], f["partial"])
+                ops.clip_adam(f["p"], f["g"], f["m"], f["v"], f["partial"], scale, group["max_grad_norm"], group["lr"], b1, b2,
+                              group["eps"], f["step"], f["norm"])
             for p in f["params"]:
                 self.state[p]["step"] += 1
         L.PARAM_EPOCH[0] += 1      # packed bf16 / transposed weight shadows must be refreshed

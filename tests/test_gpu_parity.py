@@ -455,6 +455,52 @@ def test_long_sequence_config_seq256_vocab64():
     assert abs(out[0][0] - float(loss.detach())) < 1e-4 * abs(float(loss.detach())) and torch.equal(mub, mu)
 
 
+def test_long_sequence_config_full_size_batch2048():
+    """BASELINE.json configs[4] at its FULL size -- seq_len 256, vocab 64, batch 2048 (K = T*B = 524288 rows in the weight-gradient
+    contractions: operands beyond one 2 GiB buffer descriptor, chunked inside the launcher): one complete optimiser step, twice from the
+    same state.  Size-independent properties: probability rows, the fused loss against a plain evaluation of train.py:31-38 on the same
+    recon, bitwise run-to-run determinism of loss / gradient norm / updated parameters, finite non-zero gradients for every parameter,
+    and the weight gradient of the top decoder layer against a direct f32 contraction of the saved K-major operands on a row slice."""
+    Lq, V, B = 256, 64, 2048
+    gen = torch.Generator().manual_seed(77)
+    idx = torch.randint(0, V, (B, Lq), generator=gen).to(dev)
+    eps = (1e-2 * torch.randn(B, 292, generator=gen)).to(dev)
+    ohe = torch.nn.functional.one_hot(idx, V).float()
+    loss_fn = mv.make_loss_function(Lq)
+    res = []
+    for rep in range(2):
+        torch.manual_seed(42)
+        model = mv.MolecularVAE(i=Lq, c=V).to(dev)
+        opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0)
+        opt.zero_grad(set_to_none=True)
+        recon, mu, lv = model(idx, eps)
+        loss = loss_fn(recon, ohe, mu, lv)
+        loss.backward()
+        if rep == 0:
+            assert torch.allclose(recon.sum(-1), torch.ones(B, Lq, device=dev), atol=1e-5) and float(recon.min()) >= 0
+            bce = torch.nn.functional.binary_cross_entropy(recon.reshape(-1), ohe.reshape(-1))
+            ref_loss = Lq * bce - 0.5 * torch.mean(1. + mu - lv ** 2 - torch.exp(mu))
+            assert abs(float(loss) - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+            for n, p_ in model.named_parameters():
+                g = p_.grad
+                assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0, n
+            # dW_hh of the top layer = dG[3][1:]^T . hs[3][:-1]: check 64 output rows against a direct contraction (f32, chunked over time)
+            ws = model.decoder._ws
+            dG = [b for k, b in ws.bufs.items() if k[0] == "dG3"][0]; hs = [b for k, b in ws.bufs.items() if k[0] == "hs3"][0]
+            ref = torch.zeros(64, 1024, device=dev)
+            for t in range(1, Lq):
+                ref += dG[t, :, 4096 - 64:4096].float().t() @ hs[t - 1, :, :1024].float()
+            got = model.decoder.gru.weight_hh_l3.grad[4096 - 64:4096]
+            assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+        opt.step()
+        torch.cuda.synchronize()
+        res.append((float(loss.detach()), float(opt.last_grad_norm), float(sum(p_.detach().double().abs().sum() for p_ in model.parameters()))))
+        del model, opt, recon, mu, lv, loss
+        ops.release_caches()
+        torch.cuda.empty_cache()
+    assert res[0] == res[1] and np.isfinite(res[0][0]) and res[0][1] > 0
+
+
 # ---------------------------------------------------------------------------------------------- MOSES GRU path (mosesvae.py)
 def _moses_setup(golden_dir, dtype):
     from molecular_vae_amd import mosesvae as MV, vocab as VC
