@@ -827,7 +827,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       // measured (4 x 1024, us / launch, this tile vs the 128 x (64 x 4) wave-specialised kernel): B=1024 67 vs 76, B=512 42.7 vs 42.9,
       // B=256 (32 x 128) 29.4 vs 28.5 -> not chosen, B=128 (32 x 64) 19.5 vs 21.0
       // in situ (whole training step, tests/ab_step.py): B=1024 -- this tile; B=512 (64 x 128) 18.66 vs 18.54 ms / step -> not chosen
-      const bool chosen = gm_knob == 1 && B >= cand[c][1] && tiles >= 192 && c != 2 && c != 1;
+      const bool chosen = gm_knob == 1 && tiles >= 192 && ((c == 0 && B >= 256) || (c == 3 && B >= 64 && B <= 128));
       if (gm_knob == cand[c][0] * 1000 + cand[c][1] || chosen) { BMW = cand[c][0]; BNB = cand[c][1]; }
     }
   }

@@ -409,10 +409,8 @@ class _EncoderFn(torch.autograd.Function):
         mulv, d = W("mulv", (B, 2 * o)), W("d", (B, 512))
         dmulv = W("dmulv", (B, 2 * o))
         ops.lambda_bwd(mulv, eps, dz, dmu, dlogv, dmulv, B, o)
-        dmulvT, dT = W("dmulvT", (2 * o, Bp)), W("dT", (512, Bp))
-        ops.cast_transpose(dmulv, B, 2 * o, dstT=dmulvT); ops.cast_transpose(d, B, 512, dstT=dT)
         dWml = W("dWml", (2 * o, 512)); dbml = W("dbml", (2 * o,))
-        ops.gemm_nt(dmulvT, dT, dWml, 2 * o, 512, Bp)
+        ops.gemm_tn(dmulv, d, dWml, 2 * o, 512, B)               # dW = dy^T . x straight from the batch-major operands (exact-f32 TN kernel)
         ops.colsum(dmulv, B, 2 * o, dbml)
         grads["lmbd.z_mean.weight"].copy_(dWml[:o]); grads["lmbd.z_log_var.weight"].copy_(dWml[o:])
         grads["lmbd.z_mean.bias"].copy_(dbml[:o]); grads["lmbd.z_log_var.bias"].copy_(dbml[o:])
@@ -423,12 +421,11 @@ class _EncoderFn(torch.autograd.Function):
         d1 = mod.dense_1[0]
         F = d1.in_features
         flat = W("flat", (B, F))
-        ddT, flatT = W("ddT", (512, Bp)), W("flatT", (F, Bp))
-        ops.cast_transpose(dd, B, 512, dstT=ddT); ops.cast_transpose(flat, B, F, dstT=flatT)
-        ops.gemm_nt(ddT, flatT, grads["dense_1.0.weight"], 512, F, Bp)
+        ops.gemm_tn(dd, flat, grads["dense_1.0.weight"], 512, F, B)
         ops.colsum(dd, B, 512, grads["dense_1.0.bias"])
         dflat = W("dflat", (B, F))
         ops.gemm_nt(dd, P["W1T"], dflat, B, F, 512)
+        ops.run_deferred(0)       # the decoder's upper-layer weight-gradient GEMMs: from here on our own launches are chip-filling too
         # K3 backward
         c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
         k = c1.kernel_size
@@ -455,7 +452,7 @@ class _EncoderFn(torch.autograd.Function):
         gates = [W(f"gates{l}", (Lq, B, G4)) for l in range(NL)]
         dG = [W(f"dG{l}", (Lq, B, G4)) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
-        ops.run_deferred()        # the decoder's parked weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
+        ops.run_deferred(1)       # the decoder's remaining weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
         ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, Hp, cs, gates,
                     dG, dstate, tag="enc_lstm_bwd")
         _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp)
@@ -664,31 +661,22 @@ class _DecoderFn(torch.autograd.Function):
         fork = bool(mod.overlap_weight_grads and peer is not None and ctx.from_peer and ctx.needs_input_grad[1] and
                     all(p.grad is None for p in params))
         if fork:
-            e1 = torch.cuda.Event(); e1.record()
             side = mod._side_stream(dev)
-            side.wait_event(e1)
             gflat.record_stream(side)
-            with torch.cuda.stream(side):
-                weight_grads(0)
-                e2 = torch.cuda.Event(); e2.record()
-            ops.PENDING.append(e2)
-            ops.DEFERRED.append((side, lambda: weight_grads(1)))
+            ops.DEFERRED.append((side, lambda: weight_grads(0), 0))      # released by the peer after its head section (see ops.DEFERRED)
+            ops.DEFERRED.append((side, lambda: weight_grads(1), 1))      # released next to the peer's row-resident LSTM backward
         else:
             weight_grads(None)
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
         dgx0 = W("dgx0", (B, ldg))           # pad columns of dG are zero, so the padded time sum is too
         ops.timesum(dG[0], Lq, B, ldg, dgx0)
         li = W("li", (B, o))
-        dgx0T, liT = W("dgx0T", (G4, Bp)), W("liT", (o, Bp))
-        ops.cast_transpose(dgx0, B, G4, dstT=dgx0T); ops.cast_transpose(li, B, o, dstT=liT)
-        ops.gemm_nt(dgx0T, liT, grads["gru.weight_ih_l0"], G4, o, Bp)
+        ops.gemm_tn(dgx0, li, grads["gru.weight_ih_l0"], G4, o, B, lda=ldg)
         dli = W("dli", (B, o))
         ops.gemm_nt(dgx0, P["Wih0T"], dli, B, o, G4)
         # K6 backward
         ops.selu_bwd(dli, li)
-        dliT, zT = W("dliT", (o, Bp)), W("zT", (o, Bp))
-        ops.cast_transpose(dli, B, o, dstT=dliT); ops.cast_transpose(z, B, o, dstT=zT)
-        ops.gemm_nt(dliT, zT, grads["latent_input.0.weight"], o, o, Bp)
+        ops.gemm_tn(dli, z, grads["latent_input.0.weight"], o, o, B)
         ops.colsum(dli, B, o, grads["latent_input.0.bias"])
         dz = torch.empty(B, o, dtype=f32, device=dev)
         ops.gemm_nt(dli, P["WliT"], dz, B, o, o, ldb=P["WliT"].stride(0))

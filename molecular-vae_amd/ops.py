@@ -40,21 +40,28 @@ class _Timed:
 PENDING = []
 
 
-# (side stream, callable): throughput-bound work its owner parked so that a peer can release it next to a latency-bound phase that leaves
-# most CUs idle (the encoder's row-resident LSTM backward).  Whoever reaches run_deferred() / join_pending() first runs it.
+# (side stream, callable, stage): throughput-bound work its owner parked so that a peer can release it at a chosen point of ITS launch
+# sequence.  The decoder parks its weight-gradient GEMMs in two stages: stage 0 is released by the encoder's backward once its head section
+# (a dozen tiny launches that would otherwise each wait for a chip-filling GEMM workgroup to retire) is enqueued, stage 1 right before its
+# row-resident LSTM backward, whose 128 workgroups leave half the CUs idle.  Whoever reaches run_deferred() / join_pending() first runs it.
 DEFERRED = []
 
 
-def run_deferred():
-    """Launch every parked piece of work on its side stream, ordered after everything issued so far on the current stream."""
+def run_deferred(stage=None):
+    """Launch the parked work of stages <= `stage` (None: all) on its side stream, ordered after everything issued so far on the current stream."""
+    keep = []
     while DEFERRED:
-        side, fn = DEFERRED.pop(0)
+        side, fn, st = DEFERRED.pop(0)
+        if stage is not None and st > stage:
+            keep.append((side, fn, st))
+            continue
         ev = torch.cuda.Event(); ev.record()
         side.wait_event(ev)
         with torch.cuda.stream(side):
             fn()
             e2 = torch.cuda.Event(); e2.record()
         PENDING.append(e2)
+    DEFERRED.extend(keep)
 
 
 def join_pending():

@@ -11,7 +11,7 @@ import re
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-KEEP = ("lstm_step_fwd_kernel", "lstm_step_bwd_kernel", "lstm_bwd_epi_kernel", "gemm_tn_bf16")
+KEEP = ("lstm_step_fwd", "lstm_step_bwd", "lstm_bwd_epi", "gemm_tn_bf16")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> [(grid, value)]
 for f in glob.glob(f"{root}/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
