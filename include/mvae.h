@@ -78,6 +78,20 @@ int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
  * all of dG).  Only for shapes that kernel serves with 4 tile columns and split-K (mvae_gemm_tn_colsum_supported: N == 1024, M >= 2048,
  * K >= 4096); otherwise MVAE_ERR_UNSUPPORTED.  fp32 C, no bias / activation. */
 int mvae_gemm_tn_colsum_supported(int M, int N, int K);
+/* Grouped form: up to 2 * MVAE_MAX_LAYERS contractions of that kind in ONE launch, each 256 x 256 output tile accumulated in registers over
+ * its problem's full K -- no split-K slabs, no reduction launch (the decoder's 7 dW_ih / dW_hh GEMMs are 7 x 64 tiles >= 256 CUs).
+ * colsum_out (optional, needs N == 1024) as above; ws >= mvae_gemm_tn_grouped_workspace bytes (two K-half column-sum partials per
+ * problem that asks for them, summed in a fixed order by a tiny second launch).  Problems must pass mvae_gemm_tn_grouped_supported. */
+typedef struct {
+  int M, N; int64_t K;
+  const void* A; int64_t lda;          /* [K, lda] bf16, K-major */
+  const void* B; int64_t ldb;          /* [K, ldb] bf16 */
+  float* C; int64_t ldc; int accumulate;
+  float* colsum_out; int colsum_accumulate;
+} mvae_gemm_tn_problem;
+int mvae_gemm_tn_grouped_supported(int M, int N, int64_t K, int64_t lda, int64_t ldb);
+size_t mvae_gemm_tn_grouped_workspace(int n, const mvae_gemm_tn_problem* problems);
+int mvae_gemm_tn_grouped(int n, const mvae_gemm_tn_problem* problems, void* ws, size_t ws_bytes, void* stream);
 size_t mvae_gemm_tn_colsum_workspace(int M, int N, int K);
 int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
                         float* colsum_out, int colsum_accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -57,6 +57,11 @@ class RnnBwdDesc(C.Structure):
                 ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32)]
 
 
+class GemmTnProblem(C.Structure):
+    _fields_ = [("M", _i), ("N", _i), ("K", _i64), ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64),
+                ("C", _vp), ("ldc", _i64), ("accumulate", _i), ("colsum_out", _vp), ("colsum_accumulate", _i)]
+
+
 # name -> (restype, argtypes); mirrors include/mvae.h one to one (tests check every symbol is exported)
 SIGNATURES = {
     "mvae_abi_version": (_i, []),
@@ -73,6 +78,9 @@ SIGNATURES = {
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
     "mvae_dropout_keep": (_i, [C.c_uint32, C.c_uint32, _f]),
     "mvae_gemm_tn_colsum_supported": (_i, [_i, _i, _i]),
+    "mvae_gemm_tn_grouped_supported": (_i, [_i, _i, _i64, _i64, _i64]),
+    "mvae_gemm_tn_grouped_workspace": (_sz, [_i, C.POINTER(GemmTnProblem)]),
+    "mvae_gemm_tn_grouped": (_i, [_i, C.POINTER(GemmTnProblem), _vp, _sz, _vp]),
     "mvae_gemm_tn_colsum_workspace": (_sz, [_i, _i, _i]),
     "mvae_gemm_tn_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
     "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),

@@ -228,6 +228,71 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(GemmArgs p) {
     }
 }
 
+// ---- grouped form: several weight-gradient contractions of one shape class in ONE launch, each 256 x 256 tile accumulated in registers
+// over its group's FULL K -- no split-K slabs, no reduce launch.  The 7 dW_ih / dW_hh GEMMs of the decoder stack are 7 x 64 tiles.
+struct TnGroup {
+  const void* A; const void* B; float* C; float* cs_partial;      // cs_partial: [2][M] K-half column-sum partials (nullptr: no column sums)
+  long lda, ldb, ldc;
+  int M, N, K, accumulate, tiles_m, tiles_n, tile0;               // tile0: first tile index of this group in the launch
+};
+struct TnGroupArgs { TnGroup g[MVAE_MAX_LAYERS * 2]; int ngroups, ntiles; };
+
+template <bool COLSUM>
+__global__ __launch_bounds__(512) void gemm_tn_bf16_256_grouped_kernel(TnGroupArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int gt = xcd_remap(blockIdx.x, p.ntiles);
+  int gi = 0;
+#pragma unroll 1
+  for (int i = 1; i < p.ngroups; ++i) if (gt >= p.g[i].tile0) gi = i;
+  const TnGroup& q = p.g[gi];
+  const int tile = gt - q.tile0;
+  const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PipeSegTN2 s;
+  pipe_seg_tn2_init(s, q.A, q.lda, m0, q.B, q.ldb, n0, q.K, tid);
+  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cs_pair = tn * 4 + wn, cs_mi = cs_pair & 7, cs_half = (COLSUM && q.cs_partial != nullptr) ? (cs_pair >> 3) : -1;
+  tile_gemm_tn_256<COLSUM>(smem, s, wm, wn, acc, cs_mi, cs_half, accb, tid);
+  const int lr = lane & 15, lq = lane >> 4;
+  if (COLSUM && cs_half >= 0 && lr == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm * 128 + cs_mi * 16 + lq * 4 + r;
+      if (row < q.M) q.cs_partial[(long)cs_half * q.M + row] = accb[r];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + lr;
+      if (col >= q.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 128 + i * 16 + lq * 4 + r;
+        if (row >= q.M) continue;
+        float* c = q.C + (long)row * q.ldc + col;
+        *c = q.accumulate ? (*c + acc[i][j][r]) : acc[i][j][r];
+      }
+    }
+}
+// out[m] (+)= partial[0][m] + partial[1][m], fixed order
+struct TnColsumFinish { const float* partial[MVAE_MAX_LAYERS * 2]; float* out[MVAE_MAX_LAYERS * 2]; int M[MVAE_MAX_LAYERS * 2], acc[MVAE_MAX_LAYERS * 2]; int n; };
+__global__ __launch_bounds__(256) void gemm_tn_colsum_finish_kernel(TnColsumFinish f) {
+  const int gi = blockIdx.y;
+  if (gi >= f.n) return;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < f.M[gi]; i += gridDim.x * 256) {
+    const float v = f.partial[gi][i] + f.partial[gi][f.M[gi] + i];
+    f.out[gi][i] = f.acc[gi] ? f.out[gi][i] + v : v;
+  }
+}
+
 namespace {
 struct Plan { int bm, tiles_m, tiles_n, splits; long kper; };
 
@@ -645,6 +710,61 @@ int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_grou
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    MVAE_CHECK_HIP(hipGetLastError());
+  }
+  return MVAE_OK;
+}
+
+
+// ---- grouped launcher (see gemm_tn_bf16_256_grouped_kernel).  Every problem: bf16 K-major operands, fp32 C, N a multiple of 256, and --
+// for column sums -- exactly 4 tile columns (N == 1024).  Operands beyond 2 GiB (K * ld * 2 bytes) are not served here.
+extern "C" int mvae_gemm_tn_grouped_supported(int M, int N, int64_t K, int64_t lda, int64_t ldb) {
+  return (M >= 256 && N >= 256 && N % 256 == 0 && K >= 64 && (lda % 8) == 0 && (ldb % 8) == 0 && K * lda * 2 < (1L << 31) && K * ldb * 2 < (1L << 31)) ? 1 : 0;
+}
+extern "C" size_t mvae_gemm_tn_grouped_workspace(int n, const mvae_gemm_tn_problem* pr) {
+  size_t b = 0;
+  for (int i = 0; i < n; ++i) if (pr[i].colsum_out) b += (size_t)2 * pr[i].M * sizeof(float);
+  return b;
+}
+extern "C" int mvae_gemm_tn_grouped(int n, const mvae_gemm_tn_problem* pr, void* ws, size_t ws_bytes, void* stream) {
+  if (n < 1 || n > MVAE_MAX_LAYERS * 2 || !pr) return MVAE_ERR_INVALID;
+  if (mvae_gemm_tn_grouped_workspace(n, pr) > ws_bytes || (mvae_gemm_tn_grouped_workspace(n, pr) && !ws)) return MVAE_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  TnGroupArgs a;
+  TnColsumFinish f;
+  f.n = 0;
+  float* wsp = reinterpret_cast<float*>(ws);
+  int tiles = 0, maxM = 0;
+  bool any_cs = false;
+  for (int i = 0; i < n; ++i) {
+    const mvae_gemm_tn_problem& q = pr[i];
+    if (!q.A || !q.B || !q.C) return MVAE_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) return MVAE_ERR_INVALID;
+    if (!mvae_gemm_tn_grouped_supported(q.M, q.N, q.K, q.lda, q.ldb)) return MVAE_ERR_UNSUPPORTED;
+    TnGroup& g = a.g[i];
+    g.A = q.A; g.B = q.B; g.C = q.C; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.M = q.M; g.N = q.N; g.K = (int)q.K; g.accumulate = q.accumulate;
+    g.tiles_m = (q.M + 255) / 256; g.tiles_n = q.N / 256; g.tile0 = tiles; g.cs_partial = nullptr;
+    if (q.colsum_out) {
+      if (g.tiles_n != 4) return MVAE_ERR_UNSUPPORTED;
+      g.cs_partial = wsp; wsp += (size_t)2 * q.M;
+      f.partial[f.n] = g.cs_partial; f.out[f.n] = q.colsum_out; f.M[f.n] = q.M; f.acc[f.n] = q.colsum_accumulate; ++f.n;
+      any_cs = true;
+      if (q.M > maxM) maxM = q.M;
+    }
+    tiles += g.tiles_m * g.tiles_n;
+  }
+  a.ngroups = n; a.ntiles = tiles;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_grouped_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_grouped_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (any_cs) hipLaunchKernelGGL(gemm_tn_bf16_256_grouped_kernel<true>, dim3(tiles), dim3(512), 2 * 65536, st, a);
+  else hipLaunchKernelGGL(gemm_tn_bf16_256_grouped_kernel<false>, dim3(tiles), dim3(512), 2 * 65536, st, a);
+  MVAE_CHECK_HIP(hipGetLastError());
+  if (any_cs) {
+    hipLaunchKernelGGL(gemm_tn_colsum_finish_kernel, dim3((maxM + 255) / 256, f.n), dim3(256), 0, st, f);
     MVAE_CHECK_HIP(hipGetLastError());
   }
   return MVAE_OK;

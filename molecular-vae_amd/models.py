@@ -177,6 +177,24 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
     G4, TB = 4 * H, Lq * B
     f32 = torch.float32
     layers = range(NL) if layers is None else layers
+    if dt == torch.bfloat16 and Lq > 1 and ops.gemm_tn_grouped_supported(dG[0], G4, H, TB - B, ldg, ldh) and H == 1024 and os.environ.get("MVAE_DW_GROUPED", "1") != "0":
+        # ONE grouped launch for every dW_ih / dW_hh of the requested layers (64 tiles of 256 x 256 each, accumulated over the full K = T*B in
+        # registers: no split-K slabs, no reduction launch); the bias gradient (column sums of dG) rides along one GEMM per layer.
+        probs = []
+        for l in layers:
+            a = dG[l].view(TB, ldg)
+            db = grads[f"{prefix}.bias_ih_l{l}"]
+            if l > 0:
+                probs.append(dict(A=a, B=hs[l - 1].view(TB, ldh), out=grads[f"{prefix}.weight_ih_l{l}"], M=G4, N=H, K=TB, lda=ldg, ldb=ldh, colsum_out=db))
+                probs.append(dict(A=a[B:], B=hs[l].view(TB, ldh), out=grads[f"{prefix}.weight_hh_l{l}"], M=G4, N=H, K=TB - B, lda=ldg, ldb=ldh))
+            else:
+                ops.colsum_t(a[:B], B, G4, db, ldx=ldg)             # the first time step's rows (the shifted GEMM skips them)
+                probs.append(dict(A=a[B:], B=hs[l].view(TB, ldh), out=grads[f"{prefix}.weight_hh_l{l}"], M=G4, N=H, K=TB - B, lda=ldg, ldb=ldh,
+                                  colsum_out=db, colsum_accumulate=True))
+        ops.gemm_tn_grouped(probs)
+        for l in layers:
+            grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
+        return
     if dt == torch.bfloat16:
         for l in layers:
             a = dG[l].view(TB, ldg)

@@ -141,6 +141,29 @@ def gemm_tn_colsum(A, B, out, colsum_out, M, N, K, lda=None, ldb=None, colsum_ac
     return True
 
 
+def gemm_tn_grouped_supported(A, M, N, K, lda, ldb):
+    return A.dtype == torch.bfloat16 and bool(L.load().mvae_gemm_tn_grouped_supported(M, N, K, lda, ldb))
+
+
+def gemm_tn_grouped(problems):
+    """problems: list of dict(A, B, out, M, N, K, lda, ldb[, colsum_out, colsum_accumulate, accumulate]) -- bf16 K-major operands; ONE launch
+    for all of them, each 256 x 256 tile accumulated over its full K (no split-K slabs / reduction launch)."""
+    lib = L.load()
+    n = len(problems)
+    arr = (L.GemmTnProblem * n)()
+    for i, q in enumerate(problems):
+        a = arr[i]
+        a.M, a.N, a.K = q["M"], q["N"], q["K"]
+        a.A, a.lda, a.B, a.ldb = q["A"].data_ptr(), q["lda"], q["B"].data_ptr(), q["ldb"]
+        a.C, a.ldc, a.accumulate = q["out"].data_ptr(), q["out"].stride(0), 1 if q.get("accumulate") else 0
+        cs = q.get("colsum_out")
+        a.colsum_out = cs.data_ptr() if cs is not None else None
+        a.colsum_accumulate = 1 if q.get("colsum_accumulate") else 0
+    need = lib.mvae_gemm_tn_grouped_workspace(n, arr)
+    ws = Scratch.get(need, problems[0]["A"].device, tag="tn_grouped") if need else None
+    check(lib.mvae_gemm_tn_grouped(n, arr, ptr(ws), need, stream_ptr()), "mvae_gemm_tn_grouped")
+
+
 def colsum_t(X, M, N, out, ldx=None):
     lib = L.load()
     need = lib.mvae_colsum_t_workspace(M, N)

@@ -143,6 +143,32 @@ def test_gemm_tn_colsum_fused(shape):
     assert not ops.gemm_tn_colsum_supported(A, 35, 1024, K)  # small shapes: the caller falls back to gemm_tn + colsum_t
 
 
+def test_gemm_tn_grouped_one_launch_no_split_k():
+    """The grouped weight-gradient launch: several C = A^T . B problems of different K (and operand offsets) in one grid, each 256 x 256 tile
+    accumulated over its full K, column sums of A riding along (fresh and accumulated), accumulate onto C -- against f64 on the same bf16 inputs."""
+    rs = np.random.RandomState(3)
+    M, N, lda, ldb = 4096, 1024, 4096 + 64, 1024 + 64
+    Ks = [700, 520, 1000]
+    A = [t(rs.standard_normal((K, lda)) * 0.1, torch.bfloat16) for K in Ks]
+    Bm = [t(rs.standard_normal((K, ldb)) * 0.1, torch.bfloat16) for K in Ks]
+    outs = [torch.full((M, N), float("nan"), device=dev), torch.full((M, N), float("nan"), device=dev), torch.ones(M, N, device=dev)]
+    cs0 = torch.full((M,), float("nan"), device=dev); cs2 = torch.full((M,), 2.0, device=dev)
+    probs = [dict(A=A[0], B=Bm[0], out=outs[0], M=M, N=N, K=Ks[0], lda=lda, ldb=ldb, colsum_out=cs0),
+             dict(A=A[1][8:], B=Bm[1], out=outs[1], M=M, N=N, K=Ks[1] - 8, lda=lda, ldb=ldb),
+             dict(A=A[2], B=Bm[2], out=outs[2], M=M, N=N, K=Ks[2], lda=lda, ldb=ldb, accumulate=True, colsum_out=cs2, colsum_accumulate=True)]
+    assert all(ops.gemm_tn_grouped_supported(q["A"], M, N, q["K"], lda, ldb) for q in probs)
+    ops.gemm_tn_grouped(probs)
+    torch.cuda.synchronize()
+    a64 = [x.double().cpu().numpy() for x in A]; b64 = [x.double().cpu().numpy() for x in Bm]
+    assert rel(outs[0].cpu().numpy(), a64[0][:, :M].T @ b64[0][:, :N]) < 2e-6
+    assert rel(outs[1].cpu().numpy(), a64[1][8:, :M].T @ b64[1][:Ks[1] - 8, :N]) < 2e-6
+    assert rel(outs[2].cpu().numpy(), 1.0 + a64[2][:, :M].T @ b64[2][:, :N]) < 2e-6
+    assert rel(cs0.cpu().numpy(), a64[0][:, :M].sum(0)) < 2e-6 and rel(cs2.cpu().numpy(), 2.0 + a64[2][:, :M].sum(0)) < 2e-6
+    out2 = [torch.empty_like(o) for o in outs[:2]]
+    ops.gemm_tn_grouped([dict(probs[0], out=out2[0], colsum_out=None), dict(probs[1], out=out2[1])])
+    assert torch.equal(out2[0], outs[0]) and torch.equal(out2[1], outs[1])          # deterministic, independent of the grouping
+
+
 @pytest.mark.parametrize("shape", [(64, 64, 32), (300, 200, 513), (288, 72, 4000), (35, 1024, 1000), (120, 2304, 700), (5, 3, 7)])
 def test_gemm_tn_f32_exact(shape):
     """C = A^T . B from K-major f32 operands on the exact-f32 MFMA kernel (conv / encoder weight gradients): ragged M/N/K, split over K."""
