@@ -87,7 +87,7 @@ struct StepTaskF {
   const uint8_t* dmask;               // [B, H] injected keep mask of this cell (nullptr: hash)
   uint32_t didx0;                     // hash counter of element (b = 0, j = 0) of this cell
 };
-struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_j, dbg, vec, cell; DropArgs drop; };
+struct StepArgsF { StepTaskF t[MVAE_MAX_LAYERS]; const int* lengths; int ntask, B, H, tiles_m, tiles_j, dbg, vec, cell, gru3; DropArgs drop; };
 
 // NBUF > 0: LDS-direct ring of that depth; NBUF == 0: generic register-staged loop (any shape)
 // WS: 512 threads, waves 4-7 only load (tile_gemm_ws); everyone takes part in the epilogue
@@ -124,16 +124,20 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
   if constexpr (PIPE) {
     PipeSeg<BM, BN> s0, s1;
     const uint32_t sz = (uint32_t)sizeof(T);
+    // GRU gate slots are [r | z | W_in x | W_hn h]: the x segment has no rows for slot 3, the h segment none for slot 2 (zero blocks in
+    // the packed weights).  Those tile rows are given out-of-range offsets: the descriptor bound turns them into zeros without a fetch --
+    // a quarter of the weight stream of a GRU step.
+    const int skip0 = p.gru3 ? 3 : -1, skip1 = p.gru3 ? 2 : -1;
     {
       const uint32_t lda = (uint32_t)q.lda0 * sz, ldw = (uint32_t)q.ldw0 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
-      auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
+      auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return (j < H && g != skip0) ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)(4 * H) * ldw, offA, offB, q.K0, tid & 255);
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
-      auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
+      auto offB = [&](int r) -> uint32_t { const int g = r / BJ, j = j0 + (r - g * BJ); return (j < H && g != skip1) ? (uint32_t)(g * H + j) * ldw : PIPE_OOB; };
       pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)(4 * H) * ldw, offA, offB, q.K1, tid & 255);
     }
     if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), JS, BJ>(smem, s0, s1, wm * WM, wj * (BJ / 2), acc, tid);
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
       const T* W = reinterpret_cast<const T*>(q.W0);
       const long lda = q.lda0, ldw = q.ldw0;
       auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
-      auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
+      auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return (j < H && !(p.gru3 && g == 3)) ? W + ((long)g * H + j) * ldw : nullptr; };
       tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
     }
     if (q.A1 != nullptr) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
       const T* W = reinterpret_cast<const T*>(q.W1);
       const long lda = q.lda1, ldw = q.ldw1;
       auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
-      auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return j < H ? W + ((long)g * H + j) * ldw : nullptr; };
+      auto rowB = [&](int r) -> const T* { const int g = r / BJ, j = j0 + (r - g * BJ); return (j < H && !(p.gru3 && g == 2)) ? W + ((long)g * H + j) * ldw : nullptr; };
       tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
     }
   }
@@ -434,7 +438,7 @@ struct StepTaskB {
   const uint8_t* dmask;               // [B, H] injected keep mask of this cell's OUTPUT (nullptr: hash)
   uint32_t didx0;
 };
-struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split; DropArgs drop; };
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split, gru3; DropArgs drop; };
 
 // Gate-derivative math of one (batch row, 8 hidden units) group, given dh = sum of the two contractions (fp32).
 template <typename T>
@@ -582,16 +586,24 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       const uint32_t lda = (uint32_t)q.lda0 * sz, ldw = (uint32_t)q.ldw0 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
-      const int kh = (nsp == 4) ? q.K0 / 2 : q.K0, ko = half * kh * (int)sz;         // 4-way split: this half's K range (bytes)
+      // this workgroup's K range of segment 0 (elements): everything, or one half (4-way split).  GRU: the W_hh^T rows of gate slot 2
+      // (k in [2H, 3H)) are a zero block -- skipped, as a hole in the K walk or by giving the second half only slot 3.
+      int kh = (nsp == 4) ? q.K0 / 2 : q.K0, ko = half * kh * (int)sz;
+      if (p.gru3) {
+        if (nsp == 4) { kh = half ? H : 2 * H; ko = half ? 3 * H * (int)sz : 0; }
+        else kh = 3 * H;
+      }
       pipe_seg_init<T, BM, BN>(s0, q.A0 ? reinterpret_cast<const char*>(q.A0) + ko : nullptr, (uint32_t)B * lda - ko,
                                reinterpret_cast<const char*>(q.W0) + ko, (uint32_t)H * ldw - ko, offA, offB, kh, tid & 255);
+      if (p.gru3 && nsp != 4) { s0.hole_st = (int)(2 * H * sz / KB); s0.hole_bytes = (uint32_t)H * sz; }
       if (p.split && seg == 1) s0.nk = 0;
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
-      const int kh = (nsp == 4) ? q.K1 / 2 : q.K1, ko = half * kh * (int)sz;
+      const int k1 = p.gru3 ? 3 * H : q.K1;              // GRU: the W_ih^T rows of gate slot 3 (k >= 3H) are a zero block
+      const int kh = (nsp == 4) ? k1 / 2 : k1, ko = half * kh * (int)sz;
       pipe_seg_init<T, BM, BN>(s1, q.A1 ? reinterpret_cast<const char*>(q.A1) + ko : nullptr, (uint32_t)B * lda - ko,
                                reinterpret_cast<const char*>(q.W1) + ko, (uint32_t)H * ldw - ko, offA, offB, kh, tid & 255);
       if (p.split && seg == 0) s1.nk = 0;
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       const long lda = q.lda1, ldw = q.ldw1;
       auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
       auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
-      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, p.gru3 ? 3 * H : q.K1, wm * WM, brow, acc, tid);
       scale_drop();
     }
     if (q.A0 != nullptr) {
@@ -629,7 +641,10 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       const long lda = q.lda0, ldw = q.ldw0;
       auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
       auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
-      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
+      if (p.gru3) {                                       // skip the zero block k in [2H, 3H)
+        tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, 2 * H, wm * WM, brow, acc, tid);
+        tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 3 * H, 4 * H, wm * WM, brow, acc, tid);
+      } else tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K0, wm * WM, brow, acc, tid);
     }
     if (!fused_drop && q.A1 != nullptr) {
       const T* A = reinterpret_cast<const T*>(q.A1);
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       const long lda = q.lda1, ldw = q.ldw1;
       auto rowA = [&](int r) -> const T* { const int gm = m0 + r; return gm < B ? A + (long)gm * lda : nullptr; };
       auto rowB = [&](int r) -> const T* { const int gn = n0 + r; return gn < H ? W + (long)gn * ldw : nullptr; };
-      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, q.K1, wm * WM, brow, acc, tid);
+      tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, 0, p.gru3 ? 3 * H : q.K1, wm * WM, brow, acc, tid);
     }
   }
   }
@@ -836,6 +851,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   a.drop.scale = drop ? 1.f / (1.f - d->drop_p) : 1.f;
   a.drop.thresh = drop ? (uint32_t)((double)d->drop_p * 4294967296.0) : 0u;
   a.drop.seed = d->drop_seed;
+  a.gru3 = (gru && tune_int("MVAE_GRU3", 1)) ? 1 : 0;       // GRU: never fetch the zero gate-slot block of either segment
 #ifdef MVAE_TUNING
   a.dbg = tune_int("MVAE_DBG", 0);
 #else
@@ -998,6 +1014,9 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   a.drop.scale = drop ? 1.f / (1.f - d->drop_p) : 1.f;
   a.drop.thresh = drop ? (uint32_t)((double)d->drop_p * 4294967296.0) : 0u;
   a.drop.seed = d->drop_seed;
+  // GRU: skip the zero gate-slot block of each contraction (k in [2H,3H) of dG . W_hh^T, k >= 3H of dG_up . W_ih^T); the skipped ranges
+  // must start on whole K-steps (and the 4-way split's half of 3H as well)
+  a.gru3 = (gru && tune_int("MVAE_GRU3", 1) && H % ke == 0 && (nsplit != 4 || (3 * H / 2) % ke == 0)) ? 1 : 0;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
 #ifdef MVAE_TUNING
   a.dbg = tune_int("MVAE_DBG", 0);

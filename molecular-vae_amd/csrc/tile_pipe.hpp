@@ -18,6 +18,9 @@ template <int BM, int BN, int NT = 256> struct PipeSeg {
   uint32_t offA[BM * 8 / NT];
   uint32_t offB[BN * 8 / NT];
   int nk;
+  // optional hole in the K range: local stages >= hole_st read hole_bytes further along K (a zero block of the operands that is skipped:
+  // GRU gate slots, rnn.hip).  Default: no hole.
+  int hole_st; uint32_t hole_bytes;
 };
 
 // rowoff(r) -> byte offset of tile row r (k = 0) inside the operand buffer, or PIPE_OOB.
@@ -28,6 +31,7 @@ __device__ __forceinline__ void pipe_seg_init(PipeSeg<BM, BN, NT>& s, const void
   s.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A), 0, (int)bytesA, 0x00020000);
   s.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(B), 0, (int)bytesB, 0x00020000);
   s.nk = (A != nullptr) ? K / KE : 0;
+  s.hole_st = 0x7fffffff; s.hole_bytes = 0;
 #pragma unroll
   for (int i = 0; i < BM * 8 / NT; ++i) {
     const int id = tid + i * NT, row = id >> 3, pos = id & 7;
@@ -126,7 +130,8 @@ __device__ __forceinline__ void pipe_issue_stage(char* smem, const PipeSeg<BM, B
   char* stage = smem + (st % NBUF) * ((BM + BN) * KB);
   const bool first = st < s0.nk;
   const PipeSeg<BM, BN, NT>& s = first ? s0 : s1;
-  const uint32_t kbyte = (uint32_t)(first ? st : st - s0.nk) * KB;
+  const int ls = first ? st : st - s0.nk;
+  const uint32_t kbyte = (uint32_t)ls * KB + (ls >= s.hole_st ? s.hole_bytes : 0u);
 #pragma unroll
   for (int i = 0; i < BM * 8 / NT; ++i) {
     lds_void_t* dst = (lds_void_t*)(stage + (i * NT + wave * 64) * 16);
@@ -184,7 +189,8 @@ __device__ __forceinline__ void pipe_issue_part(char* smem, const PipeSeg<BM, BN
   char* stage = smem + (st % NBUF) * ((BM + BN) * KB);
   const bool first = st < s0.nk;
   const PipeSeg<BM, BN, NT>& s = first ? s0 : s1;
-  const uint32_t kbyte = (uint32_t)(first ? st : st - s0.nk) * KB;
+  const int ls = first ? st : st - s0.nk;
+  const uint32_t kbyte = (uint32_t)ls * KB + (ls >= s.hole_st ? s.hole_bytes : 0u);
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     if (i < LO || i >= HI) continue;

@@ -248,11 +248,12 @@ class _Models2dFn(torch.autograd.Function):
         for l in range(NLAY):
             a = dG[l].view(TB, ldg)
             hprev = hsx[l][:SEQ].reshape(TB, ldh)                        # h_{t-1} for every t (slot 0 = 0)
-            _kmajor_gemm(ws, "dwhh", a, ldg, 4 * HP, hprev, ldh, HP, TB, tmp, dev)      # slots r, z, (n_x: unused), n_h
+            _kmajor_gemm(ws, "dwhh_rz", a, ldg, 2 * HP, hprev, ldh, HP, TB, tmp[:2 * HP], dev)          # slots r, z
+            _kmajor_gemm(ws, "dwhh_n", a[:, 3 * HP:], ldg, HP, hprev, ldh, HP, TB, tmp[3 * HP:], dev)    # slot n_h (slot n_x has no W_hh rows)
             gw = grads[f"gru.weight_hh_l{l}"]
             gw[0:HID].copy_(tmp[0:HID, :HID]); gw[HID:2 * HID].copy_(tmp[HP:HP + HID, :HID]); gw[2 * HID:].copy_(tmp[3 * HP:3 * HP + HID, :HID])
             if l > 0:
-                _kmajor_gemm(ws, "dwih", a, ldg, 4 * HP, hsx[l - 1][1:].reshape(TB, ldh), ldh, HP, TB, tmp, dev)   # slots r, z, n_x
+                _kmajor_gemm(ws, "dwih", a, ldg, 3 * HP, hsx[l - 1][1:].reshape(TB, ldh), ldh, HP, TB, tmp[:3 * HP], dev)   # slots r, z, n_x
                 gw = grads[f"gru.weight_ih_l{l}"]
                 gw[0:HID].copy_(tmp[0:HID, :HID]); gw[HID:2 * HID].copy_(tmp[HP:HP + HID, :HID]); gw[2 * HID:].copy_(tmp[2 * HP:2 * HP + HID, :HID])
             ops.colsum_t(a, TB, 4 * HP, s4, ldx=ldg)
