@@ -515,18 +515,37 @@ __global__ __launch_bounds__(256) void permute102_kernel(int T_, int B, int V, c
   }
 }
 // z = mu + exp(logvar/2) * eps ; kl = 0.5 * mean_b sum_j (exp(logvar) + mu^2 - 1 - logvar)      (mosesvae.py:158-162)
-__global__ __launch_bounds__(256) void moses_latent_fwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z,
-                                                               float* kl_out) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void moses_latent_fwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z,
+                                                                float* kl_out) {
+  // single block (deterministic order; B*dz is small, <= a few 1e5) of 1024 threads, four independent elements in flight per thread
+  __shared__ float red[16];
   const long n = (long)B * dz;
-  float a = 0.f;
-  for (long i = threadIdx.x; i < n; i += 256) {            // single block: deterministic, B*dz is small (<= a few 1e5)
-    const float m = mu[i], lv = logvar[i];
-    z[i] = m + expf(lv * 0.5f) * eps[i];
-    a += expf(lv) + m * m - 1.f - lv;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long i0 = threadIdx.x; i0 < n; i0 += 4096) {
+    float m[4], lv[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + 1024 * u;
+      const bool ok = i < n;
+      m[u] = ok ? mu[i] : 0.f; lv[u] = ok ? logvar[i] : 0.f; e[u] = ok ? eps[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + 1024 * u;
+      if (i < n) {
+        z[i] = m[u] + expf(lv[u] * 0.5f) * e[u];
+        a[u] += expf(lv[u]) + m[u] * m[u] - 1.f - lv[u];
+      }
+    }
   }
-  a = block_sum_256(a, red);
-  if (threadIdx.x == 0) kl_out[0] = 0.5f * a / (float)B;
+  float v = wave_sum((a[0] + a[1]) + (a[2] + a[3]));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    kl_out[0] = 0.5f * t / (float)B;
+  }
 }
 __global__ __launch_bounds__(256) void moses_latent_bwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps,
                                                                const float* dzv, const float* dkl, const float* dlogvar_ext, float* dmu, float* dlogvar) {
@@ -712,7 +731,7 @@ int mvae_permute102(int T, int B, int V, const float* in, float* out, void* stre
 }
 int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* stream) {
   if (!mu || !logvar || !eps || !z || !kl_out || B < 1 || dz < 1) return MVAE_ERR_INVALID;
-  hipLaunchKernelGGL(moses_latent_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, dz, mu, logvar, eps, z, kl_out);
+  hipLaunchKernelGGL(moses_latent_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, dz, mu, logvar, eps, z, kl_out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

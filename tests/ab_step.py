@@ -18,10 +18,38 @@ ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--set", action="append", default=[])
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--model", default="molvae", choices=["molvae", "moses", "models2d"])
 args = ap.parse_args()
 settings = [dict(kv.split("=") for kv in s.split(",") if kv) for s in (args.set or [""])]
 dev = torch.device("cuda")
 torch.manual_seed(42)
+if args.model != "molvae":
+    # the secondary workloads of bench.py (bench_extra.py): same step, same data, knobs flipped between rounds
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_extra
+    W = {"moses": bench_extra.MosesWorkload, "models2d": bench_extra.Models2dWorkload}[args.model]
+    wl = W(args.batch, "bf16", dev, 0, None)
+    keys = sorted({k for s in settings for k in s})
+    res = {i: [] for i in range(len(settings))}
+    for _ in range(3):
+        wl.step()
+    for r in range(args.rounds):
+        for i, s in enumerate(settings):
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(s)
+            wl.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                wl.step()
+            torch.cuda.synchronize()
+            res[i].append((time.perf_counter() - t0) / args.steps * 1e3)
+            print(f"round {r} {s}: {res[i][-1]:.3f} ms/step", flush=True)
+    for i, s in enumerate(settings):
+        v = sorted(res[i])
+        print(f"{s}: median {v[len(v) // 2]:.3f} min {v[0]:.3f} ms/step")
+    sys.exit(0)
 model = mv.MolecularVAE().to(dev)
 opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0)
 loss_fn = mv.make_loss_function(120)
