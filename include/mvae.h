@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 2
+#define MVAE_ABI_VERSION 3
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -49,6 +49,9 @@ extern "C" {
 #define MVAE_MAX_LAYERS 8
 
 int mvae_abi_version(void);
+/* sizeof of the descriptor structs as THIS library was compiled (0: mvae_rnn_fwd_desc, 1: mvae_rnn_bwd_desc, 2: mvae_gemm_tn_problem;
+ * anything else: 0) -- a binding checks its own mirror of the structs against it at load time. */
+size_t mvae_struct_size(int which);
 const char* mvae_status_string(int status);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -116,6 +119,10 @@ int mvae_gather_rows_tb(const int64_t* idx, int B, int L, int nrows, const float
 int mvae_scatter_rows_tb(int dtype, const int64_t* idx, int B, int L, int nrows, const void* d, int64_t ldd, int W,
                          float* dtable, void* ws, size_t ws_bytes, void* stream);
 size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W);
+/* out[(t*B + b), c] = (idx[b*L + t] == c) ? 1 : 0  for c < ld (bf16 [L*B, ld], ld >= nrows, ld % 8 == 0; ids clamped as in the gather).
+ * With it the scatter above is the TN contraction  dtable = out^T . d  (mvae_gemm_tn, M = nrows): the bf16 gradient sequence is read
+ * once at GEMM streaming rate and summed in fp32 by the MFMAs. */
+int mvae_onehot_tb(const int64_t* idx, int B, int L, int nrows, void* out, int64_t ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Recurrent stack (K2, K7, K10, K12 of SURVEY.md): torch.nn.LSTM / nn.GRU, batch-major module semantics,
@@ -128,7 +135,10 @@ size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W);
  *
  * Layer 0 input is either a real sequence x0 [T*B, in0] (dtype) or a precomputed fp32 pre-activation
  * addend add0 (row (t*B+b) at add0 + t*add0_tstride + b*G*H; tstride 0 = time-invariant input, models.py:163
- * Repeat), or both.  bias[l] (fp32 [G*H]) is added for layers whose input is a real sequence.
+ * Repeat), or both.  A token input that was folded into W_ih (embedding . W_ih^T = a [rows, G*H] fp32 table, mosesvae.py:150-153,
+ * 176-188) is given as add_table + add_index: cell (0, t) adds table row add_index[b * add_index_ld + t] to row b in its epilogue,
+ * on top of add0 -- the gathered [T, B, G*H] sequence is never written.  bias[l] (fp32 [G*H]) is added for layers whose input is a
+ * real sequence.
  *
  * Saved for backward (all caller-allocated):
  *   hs[l]     [T][B][ldh]   dtype   layer outputs h_t          (hs[layers-1] is the stack output)
@@ -144,6 +154,7 @@ typedef struct {
   int cell, dtype, layers, T, B, H, in0;
   const void* x0; int64_t x0_ld;
   const float* add0; int64_t add0_tstride;
+  const float* add_table; const int64_t* add_index; int64_t add_index_ld; int add_table_rows;   /* optional (NULL): see above; ids are clamped to the table */
   const void* w_ih[MVAE_MAX_LAYERS]; int64_t ldw_ih[MVAE_MAX_LAYERS];   /* [G*H, in] (w_ih[0] unused when x0 == NULL) */
   const void* w_hh[MVAE_MAX_LAYERS]; int64_t ldw_hh[MVAE_MAX_LAYERS];   /* [G*H, H] */
   const float* bias[MVAE_MAX_LAYERS];                                    /* LSTM: b_ih+b_hh [4H]; GRU: [b_ir+b_hr; b_iz+b_hz; b_in; b_hn] [4H] */

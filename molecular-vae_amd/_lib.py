@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # run with any MVAE_* variable set, so a measured number always comes from the product library.
 LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MVAE_F32, MVAE_BF16 = 0, 1
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
 CELL_LSTM, CELL_GRU = 0, 1
@@ -25,6 +25,7 @@ _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 class RnnFwdDesc(C.Structure):
     _fields_ = [("cell", _i), ("dtype", _i), ("layers", _i), ("T", _i), ("B", _i), ("H", _i), ("in0", _i),
                 ("x0", _vp), ("x0_ld", _i64), ("add0", _vp), ("add0_tstride", _i64),
+                ("add_table", _vp), ("add_index", _vp), ("add_index_ld", _i64), ("add_table_rows", _i),
                 ("w_ih", _vp * MAX_LAYERS), ("ldw_ih", _i64 * MAX_LAYERS),
                 ("w_hh", _vp * MAX_LAYERS), ("ldw_hh", _i64 * MAX_LAYERS),
                 ("bias", _vp * MAX_LAYERS),
@@ -65,6 +66,7 @@ class GemmTnProblem(C.Structure):
 # name -> (restype, argtypes); mirrors include/mvae.h one to one (tests check every symbol is exported)
 SIGNATURES = {
     "mvae_abi_version": (_i, []),
+    "mvae_struct_size": (_sz, [_i]),
     "mvae_status_string": (C.c_char_p, [_i]),
     "mvae_gemm_nt_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_gemm_nt": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp, _sz, _vp]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "mvae_gather_rows_tb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
+    "mvae_onehot_tb": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
     "mvae_dropout_keep": (_i, [C.c_uint32, C.c_uint32, _f]),
     "mvae_gemm_tn_colsum_supported": (_i, [_i, _i, _i]),
@@ -142,6 +145,9 @@ def load():
         fn.argtypes = args
     if lib.mvae_abi_version() != ABI_VERSION:
         raise MvaeError("libmvae_hip.so ABI version mismatch")
+    for which, st in enumerate((RnnFwdDesc, RnnBwdDesc, GemmTnProblem)):
+        if lib.mvae_struct_size(which) != C.sizeof(st):
+            raise MvaeError(f"{st.__name__}: ctypes mirror is {C.sizeof(st)} bytes, the library's struct {lib.mvae_struct_size(which)}")
     _lib = lib
     return lib
 

@@ -9,6 +9,14 @@ size_t rnn_bwd_workspace_bytes(const mvae_rnn_bwd_desc* d);
 extern "C" {
 
 int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+size_t mvae_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(mvae_rnn_fwd_desc);
+    case 1: return sizeof(mvae_rnn_bwd_desc);
+    case 2: return sizeof(mvae_gemm_tn_problem);
+    default: return 0;
+  }
+}
 
 const char* mvae_status_string(int status) {
   switch (status) {

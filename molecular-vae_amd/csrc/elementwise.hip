@@ -620,6 +620,22 @@ __global__ __launch_bounds__(256) void ce_tb_bwd_kernel(int B, int T_, int V, co
   }
 }
 
+// one thread per (row, 8-column group): 16-byte stores
+__global__ __launch_bounds__(256) void onehot_tb_kernel(const int64_t* idx, int B, int L, int nrows, bf16_t* out, long ld) {
+  const int gpr = (int)(ld / 8);
+  const long n = (long)B * L * gpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / gpr; const int c0 = (int)(i - row * gpr) * 8;
+    const int t = (int)(row / B), b = (int)(row - (long)t * B);
+    long id = idx[(long)b * L + t];
+    id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    const int e = (int)id - c0;
+    if (e >= 0 && e < 8) w[e >> 1] = (e & 1) ? 0x3F800000u : 0x00003F80u;      // bf16 1.0 in the low / high half
+    *reinterpret_cast<uint4*>(out + row * ld + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- extern "C" surface
 extern "C" {
 
@@ -686,6 +702,13 @@ int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void
       hipLaunchKernelGGL(timesum_bf16x8_kernel, dim3(grid_for(BW / 8, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
     else hipLaunchKernelGGL((timesum_kernel<bf16_t>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
   } else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_onehot_tb(const int64_t* idx, int B, int L, int nrows, void* out, int64_t ld, void* stream) {
+  if (!idx || !out || B < 1 || L < 1 || nrows < 1 || ld < nrows || (ld % 8) || (reinterpret_cast<uintptr_t>(out) & 15)) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(onehot_tb_kernel, dim3(grid_for((long)B * L * (ld / 8))), dim3(256), 0, (hipStream_t)stream, idx, B, L, nrows,
+                     reinterpret_cast<bf16_t*>(out), (long)ld);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

@@ -76,6 +76,8 @@ struct StepTaskF {
   long lda0, lda1, ldw0, ldw1;
   int K0, K1;
   const float* add; long add_ld;      // fp32 row-wise pre-activation addend (layer 0) or nullptr
+  const float* add_tbl;               // fp32 [rows][4H] table: row add_idx[b * add_idx_ld] is added on top (embedding folded into W_ih), or nullptr
+  const int64_t* add_idx; long add_idx_ld; int add_rows;
   const float* bias;                  // fp32 [4H] or nullptr
   const float* c_prev; float* c_out;  // fp32 recurrent cell state (ping-pong)
   void* c_save;                       // [B,H] dtype: cell state saved for backward
@@ -230,7 +232,23 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
       pre[g][0] = a.x + bias[g][0]; pre[g][1] = a.y + bias[g][1]; pre[g][2] = a.z + bias[g][2]; pre[g][3] = a.w + bias[g][3];
       pre[g][4] = b.x + bias[g][4]; pre[g][5] = b.y + bias[g][5]; pre[g][6] = b.z + bias[g][6]; pre[g][7] = b.w + bias[g][7];
     }
-    if (q.add) {
+    if (q.add_tbl) {        // token table (a few hundred KB, L2-resident): the [T, B, 4H] gathered copy is never materialised
+      long id = q.add_idx[(long)row * q.add_idx_ld];
+      id = id < 0 ? 0 : (id >= q.add_rows ? q.add_rows - 1 : id);
+      const float* tr = q.add_tbl + id * 4L * H + j8;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a[8], b[8];
+        ldn<float>(tr + g * H, a, n, vec);
+        if (q.add) {        // (table row + per-sequence addend) first, as mvae_gather_rows_tb forms it: same bits as the gathered path
+          ldn<float>(q.add + (long)row * q.add_ld + g * H + j8, b, n, vec);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre[g][e] += a[e];
+      }
+    } else if (q.add) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float a[8];
@@ -780,7 +798,8 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     if (l > 0 && d->ldw_ih[l] % epc) return MVAE_ERR_INVALID;
   }
   if (d->x0 && (!d->w_ih[0] || d->in0 < 1)) return MVAE_ERR_INVALID;
-  if (!d->x0 && !d->add0) return MVAE_ERR_INVALID;
+  if (!d->x0 && !d->add0 && !d->add_table) return MVAE_ERR_INVALID;
+  if (d->add_table && (!d->add_index || d->add_table_rows < 1 || d->add_index_ld < T)) return MVAE_ERR_INVALID;
   if (d->ldh % epc) return MVAE_ERR_INVALID;
   // inter-layer dropout: every layer but the last gets a dropped copy of its output, all or none
   bool drop = false;
@@ -814,7 +833,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   bool pipe = (Hk % ke == 0) && (d->ldh % (16 / sz) == 0) && ((long)B * d->ldh * sz < (1L << 31)) && (!d->x0 || (d->in0 % ke == 0 && d->x0_ld % (16 / sz) == 0)) &&
               (!d->h0[0] || d->ldh0 % (16 / sz) == 0);
   // 16-byte vector epilogue: 8-unit groups aligned in every array it touches
-  bool vec = (H % 8 == 0) && (d->ldh % 8 == 0) && (!d->add0 || (al16(d->add0) && d->add0_tstride % 4 == 0));
+  bool vec = (H % 8 == 0) && (d->ldh % 8 == 0) && (!d->add0 || (al16(d->add0) && d->add0_tstride % 4 == 0)) && (!d->add_table || al16(d->add_table));
   for (int l = 0; l < NL; ++l) {
     if ((4L * H) * d->ldw_hh[l] * sz >= (1L << 31) || d->ldw_hh[l] % (16 / sz)) pipe = false;
     if ((l > 0 || d->x0) && ((4L * H) * d->ldw_ih[l] * sz >= (1L << 31) || d->ldw_ih[l] % (16 / sz))) pipe = false;
@@ -835,7 +854,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   const int gm_knob = tune_int("MVAE_FWD_GM", 1);
   int BMW = 0, BNB = 0;
   for (int l = 0; l < NL && drop; ++l) if (d->hdrop[l] && (!al16(d->hdrop[l]))) vec = false;
-  if (gm_knob && !gru && !drop && dt == MVAE_BF16 && pipe && vec && H % 64 == 0) {
+  if (gm_knob && !gru && !drop && !d->add_table && dt == MVAE_BF16 && pipe && vec && H % 64 == 0) {
     static const int cand[4][2] = {{256, 256}, {256, 128}, {128, 128}, {128, 64}};
     for (int c = 0; c < 4 && !BMW; ++c) {
       const long tiles = (long)((B + cand[c][1] - 1) / cand[c][1]) * (H / (cand[c][0] / 4)) * NL;
@@ -873,10 +892,12 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
         q.lda0 = d->x0_ld; q.K0 = d->in0; q.W0 = d->w_ih[0]; q.ldw0 = d->ldw_ih[0];
         q.add = d->add0 ? d->add0 + (long)t * d->add0_tstride : nullptr;
         q.add_ld = 4L * H;
+        q.add_tbl = d->add_table; q.add_idx = d->add_table ? d->add_index + t : nullptr; q.add_idx_ld = d->add_index_ld; q.add_rows = d->add_table_rows;
       } else {
         q.A0 = adv(drop ? d->hdrop[l - 1] : d->hs[l - 1], (long)t * B * d->ldh, dt);     // the layer below, after its dropout
         q.lda0 = d->ldh; q.K0 = Hk; q.W0 = d->w_ih[l]; q.ldw0 = d->ldw_ih[l];
         q.add = nullptr; q.add_ld = 0;
+        q.add_tbl = nullptr; q.add_idx = nullptr; q.add_idx_ld = 0; q.add_rows = 0;
       }
       q.A1 = (t > 0) ? adv(d->hs[l], (long)(t - 1) * B * d->ldh, dt) : d->h0[l];
       q.lda1 = (t > 0) ? d->ldh : d->ldh0;

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) 
 // layers of one pass, sequentially; returns MVAE_ERR_UNSUPPORTED when the shape is not the one this schedule is built for
 int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   constexpr int H = 72;
-  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || d->x0 || !d->add0 || d->lengths) return MVAE_ERR_UNSUPPORTED;
+  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || d->x0 || !d->add0 || d->add_table || d->lengths) return MVAE_ERR_UNSUPPORTED;
   if (!d->gates[0]) return MVAE_ERR_UNSUPPORTED;      // forward-only calls (no save buffers) take the wavefront schedule
   for (int l = 0; l < d->layers; ++l)
     if (d->h0[l]) return MVAE_ERR_UNSUPPORTED;

@@ -260,13 +260,13 @@ class _MosesFn(torch.autograd.Function):
         pe = P["enc"]; Hq = pe["H"]
         tbl3 = W("enc_tbl3", (V, 3 * Hq)); ops.gemm_nt(P["E_p"], pe["Wx_p"], tbl3, V, 3 * Hq, Vp)
         tbl4 = W("enc_tbl4", (V, 4 * Hq)); tbl4[:, :3 * Hq].copy_(tbl3)
-        add_e = W("enc_add", (T, B, 4 * Hq)); ops.gather_rows_tb(x_pad, tbl4, add_e, B, T, V, 4 * Hq)
+        # the table rows are added in the step epilogue (add_table / add_index): no gathered [T, B, 4H] copy
         ldh_e = Hq + _LDPAD
         hsx_e = [W("enc_hsx0", (T + 1, B, ldh_e), dt)]                 # slot 0 = initial state (zeros), slots 1.. = outputs
         gates_e = [W("enc_gates0", (T, B, 4 * Hq), dt)]
         hstate_e = [W("enc_hstate0", (2, B, Hq))]
-        ops.rnn_fwd(L.CELL_GRU, dt, T, B, Hq, add_e, B * 4 * Hq, pe["Wih"], [pe["ldw"]], pe["Whh"], [pe["ldw"]], pe["bias"],
-                    [hsx_e[0][1:]], ldh_e, None, gates_e, hstate_e, lengths=lengths)
+        ops.rnn_fwd(L.CELL_GRU, dt, T, B, Hq, None, 0, pe["Wih"], [pe["ldw"]], pe["Whh"], [pe["ldw"]], pe["bias"],
+                    [hsx_e[0][1:]], ldh_e, None, gates_e, hstate_e, lengths=lengths, add_table=tbl4, add_index=x_pad)
         h_last = hstate_e[0][(T - 1) & 1]                               # fp32 [B,Hq]: last valid state of every sequence
         # ---------------- heads + reparameterisation + KL (mosesvae.py:158-162)
         m1 = W("m1", (B, 256)); l1 = W("l1", (B, 256)); mu = W("mu", (B, dz)); lv = W("lv", (B, dz))
@@ -283,7 +283,6 @@ class _MosesFn(torch.autograd.Function):
         tbl4d = W("dec_tbl4", (V, 4 * Hd)); tbl4d[:, :3 * Hd].copy_(tbl3d)
         zp3 = W("zp3", (B, 3 * Hd)); ops.gemm_nt(z, P["Wz"], zp3, B, 3 * Hd, dz)
         zp4 = W("zp4", (B, 4 * Hd)); zp4[:, :3 * Hd].copy_(zp3)
-        add_d = W("dec_add", (T, B, 4 * Hd)); ops.gather_rows_tb(x_pad, tbl4d, add_d, B, T, V, 4 * Hd, base=zp4)
         ldh_d = Hd + _LDPAD
         hsx_d = [W(f"dec_hsx{l}", (T + 1, B, ldh_d), dt) for l in range(NL)]
         for l in range(NL):
@@ -293,8 +292,10 @@ class _MosesFn(torch.autograd.Function):
         hd = None
         if drop is not None:                                            # train mode: dropped copies of the outputs of layers 0 .. NL-2
             hd = [W(f"dec_hd{l}", (T, B, ldh_d), dt) for l in range(NL - 1)] + [None]
-        ops.rnn_fwd(L.CELL_GRU, dt, T, B, Hd, add_d, B * 4 * Hd, pd["Wih"], [pd["ldw"]] * NL, pd["Whh"], [pd["ldw"]] * NL, pd["bias"],
+        # layer-0 input [emb(x_t), z] (mosesvae.py:176-188): z part = time-invariant addend zp4, token part = table row x[b, t]
+        ops.rnn_fwd(L.CELL_GRU, dt, T, B, Hd, zp4, 0, pd["Wih"], [pd["ldw"]] * NL, pd["Whh"], [pd["ldw"]] * NL, pd["bias"],
                     [h[1:] for h in hsx_d], ldh_d, None, gates_d, hstate_d, h0=[h[0] for h in hsx_d], ldh0=ldh_d, lengths=lengths,
+                    add_table=tbl4d, add_index=x_pad,
                     hdrop=hd, drop_mask=(None if drop is None or drop[2] is None else [drop[2][l] for l in range(NL - 1)]),
                     drop_p=(drop[0] if drop else 0.0), drop_seed=(drop[1] if drop else 0), tag="moses_dec_fwd")
         TB = T * B
@@ -381,8 +382,16 @@ class _MosesFn(torch.autograd.Function):
             grads[f"decoder_rnn.bias_ih_l{l}"].copy_(s4[:3 * Hd])
             grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
         # layer-0 input = [emb(x_t), z]: table scatter for the embedding part, time sum for the z part
-        dtbl4 = W("dec_dtbl4", (V, 4 * Hd)); ops.scatter_rows_tb(x_pad, dG_d[0], dtbl4, B, T, V, 4 * Hd, ldd=ldg_d)
-        dtbl3 = W("dec_dtbl3", (V, 3 * Hd)); dtbl3.copy_(dtbl4[:, :3 * Hd])
+        dtbl3 = W("dec_dtbl3", (V, 3 * Hd))
+        onehot = None
+        if dt == torch.bfloat16:
+            # scatter as a contraction: dtbl = onehot(x)^T . dG0 over the T*B rows -- one TN GEMM that streams the bf16 gradient once
+            onehot = W("onehot_tb", (TB + 8, Vp8), dt)[:TB]
+            ops.onehot_tb(x_pad, onehot, B, T, V)
+            ops.gemm_tn(onehot, dG_d[0].view(TB, ldg_d), dtbl3, V, 3 * Hd, TB, lda=Vp8, ldb=ldg_d)
+        else:
+            dtbl4 = W("dec_dtbl4", (V, 4 * Hd)); ops.scatter_rows_tb(x_pad, dG_d[0], dtbl4, B, T, V, 4 * Hd, ldd=ldg_d)
+            dtbl3.copy_(dtbl4[:, :3 * Hd])
         dE = W("dE", (V, V)); ops.gemm_nt(dtbl3, pd["WxT"], dE, V, V, 3 * Hd)
         dtblT = W("dec_dtblT", (3 * Hd, Vp)); ops.cast_transpose(dtbl3, V, 3 * Hd, dstT=dtblT)
         dwx = W("dec_dwx", (3 * Hd, V)); ops.gemm_nt(dtblT, P["ET_p"], dwx, 3 * Hd, V, Vp)
@@ -432,8 +441,12 @@ class _MosesFn(torch.autograd.Function):
         s4e = W("enc_s4", (4 * Hq,)); ops.colsum_t(a, TB, 4 * Hq, s4e, ldx=ldg_e)
         grads["encoder_rnn.bias_ih_l0"].copy_(s4e[:3 * Hq])
         grads["encoder_rnn.bias_hh_l0"][:2 * Hq].copy_(s4e[:2 * Hq]); grads["encoder_rnn.bias_hh_l0"][2 * Hq:].copy_(s4e[3 * Hq:])
-        etbl4 = W("enc_dtbl4", (V, 4 * Hq)); ops.scatter_rows_tb(x_pad, dG_e[0], etbl4, B, T, V, 4 * Hq, ldd=ldg_e)
-        etbl3 = W("enc_dtbl3", (V, 3 * Hq)); etbl3.copy_(etbl4[:, :3 * Hq])
+        etbl3 = W("enc_dtbl3", (V, 3 * Hq))
+        if onehot is not None:
+            ops.gemm_tn(onehot, a, etbl3, V, 3 * Hq, TB, lda=Vp8, ldb=ldg_e)
+        else:
+            etbl4 = W("enc_dtbl4", (V, 4 * Hq)); ops.scatter_rows_tb(x_pad, dG_e[0], etbl4, B, T, V, 4 * Hq, ldd=ldg_e)
+            etbl3.copy_(etbl4[:, :3 * Hq])
         dE2 = W("dE2", (V, V)); ops.gemm_nt(etbl3, pe["WxT"], dE2, V, V, 3 * Hq)
         etblT = W("enc_dtblT", (3 * Hq, Vp)); ops.cast_transpose(etbl3, V, 3 * Hq, dstT=etblT)
         ops.gemm_nt(etblT, P["ET_p"], grads["encoder_rnn.weight_ih_l0"], 3 * Hq, V, Vp)

@@ -185,6 +185,12 @@ def permute021(inp, out, N, A, Bd):
     check(L.load().mvae_permute021(N, A, Bd, ptr(inp), ptr(out), stream_ptr()), "mvae_permute021")
 
 
+def onehot_tb(idx, out, B, Lq, nrows):
+    """out[(t*B + b), c] = (idx[b, t] == c) for c < ld (bf16, time-major rows): the K-major operand that turns the table scatter
+    dtable = sum_rows onehot^T . d into one TN GEMM."""
+    check(L.load().mvae_onehot_tb(ptr(idx), B, Lq, nrows, ptr(out), out.stride(0), stream_ptr()), "mvae_onehot_tb")
+
+
 def gather_rows_tb(idx, table, out, B, Lq, nrows, W, base=None):
     check(L.load().mvae_gather_rows_tb(ptr(idx), B, Lq, nrows, ptr(table), W, ptr(base), ptr(out), stream_ptr()), "mvae_gather_rows_tb")
 
@@ -324,7 +330,8 @@ def dropout_keep_mask(seed, shape_lt_b_h, p):
 
 def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, cs, gates, cstate,
             x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, zero_padded_k=False, tag=None,
-            hdrop=None, drop_mask=None, drop_p=0.0, drop_seed=0):
+            hdrop=None, drop_mask=None, drop_p=0.0, drop_seed=0, add_table=None, add_index=None):
+    """add_table [rows, G*H] fp32 + add_index [B, L >= T] int64: layer 0 adds table row add_index[b, t] in its epilogue (no gathered copy)."""
     d = L.RnnFwdDesc()
     NL = len(w_hh)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H, d.in0 = cell, dt_code(dtype), NL, T, B, H, in0
@@ -332,6 +339,11 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
     d.x0_ld = x0_ld
     d.add0 = add0.data_ptr() if add0 is not None else None
     d.add0_tstride = add0_tstride
+    if add_table is not None:
+        assert add_table.dtype == torch.float32 and add_table.is_contiguous() and add_table.shape[1] == 4 * H
+        assert add_index.dtype == torch.int64 and add_index.stride(1) == 1
+        d.add_table, d.add_index = add_table.data_ptr(), add_index.data_ptr()
+        d.add_index_ld, d.add_table_rows = add_index.stride(0), add_table.shape[0]
     _fill(d.w_ih, w_ih); _fill(d.w_hh, w_hh); _fill(d.bias, bias)
     for i in range(NL):
         d.ldw_ih[i] = ldw_ih[i]

@@ -581,6 +581,58 @@ def test_g3_moses_gru_vae(golden_dir, dtype, tl, tg):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gru_token_table_addend_equals_gathered_sequence(dtype):
+    """mvae_rnn_fwd with add_table / add_index (+ a per-sequence addend) gives the same bits as the gathered [T, B, 4H] sequence it
+    replaces (mvae_gather_rows_tb -> add0), ragged lengths included; ids outside the table are clamped the same way."""
+    from molecular_vae_amd import _lib as LL
+    torch.manual_seed(3)
+    T, B, H, V = 9, 70, 128, 30
+    ld = H + 64
+    w = (0.1 * torch.randn(4 * H, ld, device=dev)).to(dtype); w[:, H:] = 0
+    bias = 0.1 * torch.randn(4 * H, device=dev)
+    tbl = torch.randn(V, 4 * H, device=dev); base = torch.randn(B, 4 * H, device=dev)
+    idx = torch.randint(0, V, (B, T + 3), device=dev)
+    idx[0, 0], idx[1, 2] = -4, V + 9                                   # clamped
+    lengths = torch.sort(torch.randint(1, T + 1, (B,)), descending=True).values.to(torch.int32).to(dev)
+    out = []
+    for mode in ("gathered", "table"):
+        hs = torch.zeros(T, B, ld, dtype=dtype, device=dev); gates = torch.zeros(T, B, 4 * H, dtype=dtype, device=dev)
+        hstate = torch.zeros(2, B, H, device=dev)
+        if mode == "gathered":
+            add = torch.empty(T, B, 4 * H, device=dev)
+            ops.gather_rows_tb(idx[:, :T].contiguous(), tbl, add, B, T, V, 4 * H, base=base)
+            ops.rnn_fwd(LL.CELL_GRU, dtype, T, B, H, add, B * 4 * H, [w], [ld], [w], [ld], [bias], [hs], ld, None, [gates], [hstate], lengths=lengths)
+        else:
+            ops.rnn_fwd(LL.CELL_GRU, dtype, T, B, H, base, 0, [w], [ld], [w], [ld], [bias], [hs], ld, None, [gates], [hstate], lengths=lengths,
+                        add_table=tbl, add_index=idx)
+        torch.cuda.synchronize()
+        out.append((hs.float().cpu(), gates.float().cpu(), hstate.cpu()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert out[0][0].abs().sum() > 0
+
+
+def test_token_scatter_as_onehot_contraction():
+    """dtable = onehot(x)^T . d (mvae_onehot_tb + the TN GEMM) against the deterministic scatter kernel it replaces on the bf16 path."""
+    torch.manual_seed(4)
+    B, T, V, W, ldd = 96, 21, 30, 768, 768 + 64
+    idx = torch.randint(0, V, (B, T), device=dev)
+    d = torch.randn(T * B + 8, ldd, device=dev).to(torch.bfloat16)
+    ref = torch.empty(V, W, device=dev)
+    ops.scatter_rows_tb(idx, d[:T * B].view(T, B, ldd), ref, B, T, V, W, ldd=ldd)
+    oh = torch.full((T * B + 8, 32), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.onehot_tb(idx, oh[:T * B], B, T, V)
+    want = torch.nn.functional.one_hot(idx.t().reshape(-1), 32).to(torch.bfloat16)
+    assert torch.equal(oh[:T * B], want) and (oh[T * B:] == 7.0).all()
+    oh[T * B:] = 0
+    got = torch.empty(V, W, device=dev)
+    ops.gemm_tn(oh[:T * B], d[:T * B], got, V, W, T * B, lda=32, ldb=ldd)
+    torch.cuda.synchronize()
+    exact = torch.zeros(V, W, dtype=torch.float64, device=dev).index_add_(0, idx.t().reshape(-1), d[:T * B, :W].double())
+    assert rel(got.cpu().numpy(), exact.cpu().numpy()) < 1e-6 and rel(ref.cpu().numpy(), exact.cpu().numpy()) < 1e-6
+
+
 def test_moses_larger_batch_vs_oracle():
     """B=40, lengths 12..60 (MOSES-like), V=30: GRU kernels on the LDS-direct path (H=256/512 are whole K-steps), bf16."""
     from molecular_vae_amd import mosesvae as MV, vocab as VC
