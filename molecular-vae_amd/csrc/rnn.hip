@@ -49,8 +49,11 @@ template <typename T> __device__ __forceinline__ float act_sigmoid(float x);
 template <typename T> __device__ __forceinline__ float act_tanh(float x);
 template <> __device__ __forceinline__ float act_sigmoid<float>(float x) { return 1.f / (1.f + expf(-x)); }
 template <> __device__ __forceinline__ float act_tanh<float>(float x) { return tanhf(x); }
-template <> __device__ __forceinline__ float act_sigmoid<bf16_t>(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
-template <> __device__ __forceinline__ float act_tanh<bf16_t>(float x) { return 1.f - __fdividef(2.f, 1.f + __expf(2.f * x)); }
+// bf16 storage mode: ONE v_rcp_f32 per non-linearity (1 ulp).  `a / b` and __fdividef compile to the IEEE division expansion
+// (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: ~10 VALU instructions) -- five of those per hidden unit made the
+// gate epilogues VALU-bound.
+template <> __device__ __forceinline__ float act_sigmoid<bf16_t>(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+template <> __device__ __forceinline__ float act_tanh<bf16_t>(float x) { return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)), 1.f); }
 
 __device__ __forceinline__ int xcd_remap_r(int bid, int n) {   // contiguous tile ranges per XCD (see gemm.hip)
   const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;

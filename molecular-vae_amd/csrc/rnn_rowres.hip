@@ -32,10 +32,12 @@ template <int KW, int NG> struct RowMma<KW, KW, NG> {
 };
 
 // v_exp_f32 / v_rcp_f32 forms: absolute error ~1e-7, far inside the 1e-4 the encoder outputs are held to (tests: 1e-5)
-__device__ __forceinline__ float sigm(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+// (__builtin_amdgcn_rcpf, not `/` or __fdividef: those expand to the ~10-instruction IEEE division sequence, and the gate phase is a
+// dependent chain that every one of the 120 steps waits for)
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_fast(float x) {
   const float t = __expf(-2.f * fabsf(x));
-  return copysignf(__fdividef(1.f - t, 1.f + t), x);
+  return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
 }
 // NTHR = 320: waves 0-3 run the MFMA phase (one K-slice each), all 5 waves share the gate phase (one (row, unit) item per thread).
 // NTHR = 256 where the weight fragments need more than 256 VGPRs per wave (backward with an input gradient: 216 + state).
