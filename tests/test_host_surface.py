@@ -231,3 +231,9 @@ def test_bench_refuses_world_size_mismatch_and_tuning_variables():
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
     r = _bench("--gpus", "1", "--steps", "1", env={"MVAE_DBG": "1"})
     assert r.returncode != 0 and "MVAE_DBG" in r.stderr and not r.stdout.strip()
+
+
+def test_graft_entry_build_hook_runs():
+    """The driver's "does it build" hook: compiles every HIP source for gfx950 and loads the library (no GPU needed)."""
+    import __graft_entry__ as ge
+    ge.build()
