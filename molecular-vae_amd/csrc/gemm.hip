@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_tn_colsum_finish_kernel(TnColsumFini
 }
 
 namespace {
-struct Plan { int bm, tiles_m, tiles_n, splits; long kper; };
+struct Plan { int bm, bn, tiles_m, tiles_n, splits; long kper; };
 
 Plan make_plan(int M, int N, int K, int dtype) {
   Plan pl;
@@ -304,8 +304,12 @@ Plan make_plan(int M, int N, int K, int dtype) {
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
   auto eff = [](long t) { return (double)t / (double)(((t + 255) / 256) * 256); };
   pl.bm = (t128 >= 192 && eff(t128) >= 0.8 * eff(t64)) ? 128 : 64;
+  pl.bn = pl.bm;
+  // narrow outputs in f32 (the conv stack: 9 / 10 output channels padded to 32): a 128 x 32 tile, so that the slow f32 MFMAs are not
+  // spent on the 75 % (128-wide tile) or 50 % (64-wide) of columns that lie outside the matrix
+  if (dtype == MVAE_F32 && N <= 32 && M >= 128) { pl.bm = 128; pl.bn = 32; }
   pl.tiles_m = (M + pl.bm - 1) / pl.bm;
-  pl.tiles_n = (N + pl.bm - 1) / pl.bm;
+  pl.tiles_n = (N + pl.bn - 1) / pl.bn;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   long ksteps = (K + ke - 1) / ke;
   if (ksteps < 1) ksteps = 1;                 // K == 0: one empty pass, the epilogue still writes bias / zeros
@@ -363,15 +367,18 @@ int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long l
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0) &&
                     (a_total * sz < (1L << 31)) && ((long)N * ldb * sz < (1L << 31)) && K >= 4 * ke &&
                     (a_group == 0 || a_gstride % (16 / sz) == 0);
-  const size_t lds = (size_t)(pipe ? 4 : 2) * (pl.bm + pl.bm) * KB;
-#define MVAE_GEMM_LAUNCH(TT_, BM_, PIPE_)                                                             \
+  const size_t lds = (size_t)(pipe ? 4 : 2) * (pl.bm + pl.bn) * KB;
+#define MVAE_GEMM_LAUNCH2(TT_, BM_, BN_, PIPE_)                                                       \
   do {                                                                                                \
-    auto kern = gemm_nt_kernel<TT_, BM_, BM_, PIPE_>;                                                 \
+    auto kern = gemm_nt_kernel<TT_, BM_, BN_, PIPE_>;                                                 \
     static bool attr_set = false;                                                                     \
     if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
     hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                \
   } while (0)
-  if (dtype == MVAE_BF16) {
+#define MVAE_GEMM_LAUNCH(TT_, BM_, PIPE_) MVAE_GEMM_LAUNCH2(TT_, BM_, BM_, PIPE_)
+  if (pl.bn == 32) {
+    if (pipe) MVAE_GEMM_LAUNCH2(float, 128, 32, true); else MVAE_GEMM_LAUNCH2(float, 128, 32, false);
+  } else if (dtype == MVAE_BF16) {
     if (pl.bm == 128) { if (pipe) MVAE_GEMM_LAUNCH(bf16_t, 128, true); else MVAE_GEMM_LAUNCH(bf16_t, 128, false); }
     else { if (pipe) MVAE_GEMM_LAUNCH(bf16_t, 64, true); else MVAE_GEMM_LAUNCH(bf16_t, 64, false); }
   } else {
@@ -379,6 +386,7 @@ int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long l
     else { if (pipe) MVAE_GEMM_LAUNCH(float, 64, true); else MVAE_GEMM_LAUNCH(float, 64, false); }
   }
 #undef MVAE_GEMM_LAUNCH
+#undef MVAE_GEMM_LAUNCH2
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;
