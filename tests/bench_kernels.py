@@ -76,6 +76,22 @@ if "gemmcs" in which:
     print(f"gemm+colsum: {ms:.3f} ms  M={G4} N={H} K={T * B}  {2 * G4 * H * T * B / ms / 1e9:.1f} TFLOP/s")
     ms = timeit(lambda: ops.colsum_t(dG[1].view(T * B, ldg), T * B, G4, db, ldx=ldg))
     print(f"colsum_t alone: {ms:.3f} ms")
+if "gemmg" in which.split(","):
+    # the step's own form: all dW_ih / dW_hh of the upper two layers as ONE grouped full-K launch (4 problems x 64 tiles of 256 x 256)
+    db = [torch.zeros(G4, device=dev) for _ in range(2)]
+    dWs = [torch.zeros(G4, H, device=dev) for _ in range(4)]
+    TB = T * B
+
+    def gemmg():
+        pr = []
+        for i, l in enumerate((NL - 1, NL - 2)):
+            a = dG[l].view(TB, ldg)
+            pr.append(dict(A=a, B=hs[l - 1].view(TB, ldh), out=dWs[2 * i], M=G4, N=H, K=TB, lda=ldg, ldb=ldh, colsum_out=db[i]))
+            pr.append(dict(A=a[B:], B=hs[l].view(TB, ldh), out=dWs[2 * i + 1], M=G4, N=H, K=TB - B, lda=ldg, ldb=ldh))
+        ops.gemm_tn_grouped(pr)
+    ms = timeit(gemmg)
+    fl = 2 * G4 * H * (2 * TB + 2 * (TB - B))
+    print(f"gemm grouped (4 problems, one launch): {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
 if "gemm" in which.split(","):
     ms = timeit(gemm)
     print(f"gemm: {ms:.3f} ms  M={G4} N={H} K={T * B}  {2 * G4 * H * T * B / ms / 1e9:.1f} TFLOP/s")
