@@ -139,3 +139,50 @@ def test_no_kernel_spills_to_scratch():
             if m and int(m.group(1)) > 0:
                 bad.append((name, "spill", int(m.group(1))))
     assert kernels > 50 and not bad, bad
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_device():
+    """Error behaviour of the boundary (include/mvae.h: int status, no exceptions, nothing launched): every call below must come back with
+    a negative status from the argument checks alone -- this runs on the GPU-less build container."""
+    import ctypes as C
+    lib = L.load()
+    INV, WSP, UNS = -1, -2, -3
+    assert lib.mvae_status_string(0) == b"ok" and lib.mvae_status_string(INV) == b"invalid argument"
+    assert lib.mvae_status_string(UNS) == b"unsupported combination" and lib.mvae_status_string(-77) == b"unknown status"
+    buf = (C.c_float * 4096)()
+    p = C.cast(buf, C.c_void_p)
+    # GEMMs: null operands, unknown dtype, accumulate into a bf16 output
+    assert lib.mvae_gemm_nt(L.MVAE_F32, 8, 8, 8, None, 8, p, 8, p, 8, L.MVAE_F32, None, 0, 0, None, 0, None) == INV
+    assert lib.mvae_gemm_nt(7, 8, 8, 8, p, 8, p, 8, p, 8, L.MVAE_F32, None, 0, 0, None, 0, None) == INV
+    assert lib.mvae_gemm_nt(L.MVAE_F32, 8, 8, 8, p, 8, p, 8, p, 8, L.MVAE_BF16, None, 0, 1, None, 0, None) == INV
+    assert lib.mvae_gemm_nt(L.MVAE_F32, 0, 8, 8, None, 8, None, 8, None, 8, L.MVAE_F32, None, 0, 0, None, 0, None) == 0      # empty output: nothing to do
+    assert lib.mvae_gemm_tn(7, 8, 8, 8, p, 8, p, 8, p, 8, L.MVAE_F32, None, 0, 0, None, 0, None) == UNS
+    assert lib.mvae_gemm_tn(L.MVAE_F32, 8, 8, 8, p, 8, p, 8, p, 8, L.MVAE_F32, p, 0, 0, None, 0, None) == UNS                # exact-f32 TN: no fused bias
+    assert lib.mvae_gemm_tn_grouped(0, None, None, 0, None) == INV
+    assert lib.mvae_gemm_tn_grouped_supported(4096, 1000, 61440, 4160, 1088) == 0                                        # N not a multiple of 256
+    assert lib.mvae_gemm_tn_grouped_supported(4096, 1024, 61440, 4160, 1088) == 1
+    assert lib.mvae_gemm_tn_colsum(8, 8, 8, p, 8, p, 8, p, 8, 0, None, 0, None, 0, None) == INV
+    # recurrent stacks: empty descriptor, unknown cell, zero sizes, a missing save buffer
+    d = L.RnnFwdDesc()
+    assert lib.mvae_rnn_fwd(None, None) == INV
+    d.cell = 9
+    assert lib.mvae_rnn_fwd(C.byref(d), None) == UNS
+    d.cell, d.dtype, d.layers, d.T, d.B, d.H = L.CELL_LSTM, L.MVAE_BF16, 1, 0, 4, 8
+    assert lib.mvae_rnn_fwd(C.byref(d), None) == INV
+    d.T = 3
+    assert lib.mvae_rnn_fwd(C.byref(d), None) == INV            # no weights / outputs
+    d.layers = L.MAX_LAYERS + 1
+    assert lib.mvae_rnn_fwd(C.byref(d), None) == INV
+    b = L.RnnBwdDesc()
+    assert lib.mvae_rnn_bwd(None, None) == INV
+    b.cell, b.dtype, b.layers, b.T, b.B, b.H = L.CELL_LSTM, 5, 1, 3, 4, 8
+    assert lib.mvae_rnn_bwd(C.byref(b), None) == INV
+    # helpers
+    assert lib.mvae_onehot_tb(p, 4, 4, 30, p, 30, None) == INV             # leading dimension not a multiple of 8
+    assert lib.mvae_onehot_tb(p, 4, 4, 40, p, 32, None) == INV             # table wider than the row
+    assert lib.mvae_colsum_t(L.MVAE_BF16, 16, 8, p, 12, p, p, 1 << 20, None) == INV       # ldx % 8
+    assert lib.mvae_colsum_t(L.MVAE_BF16, 16, 8, p, 16, p, None, 0, None) == WSP
+    assert lib.mvae_scatter_rows_tb(L.MVAE_F32, None, 4, 4, 30, p, 8, 8, p, None, 0, None) == INV
+    assert lib.mvae_timesum(L.MVAE_F32, 0, 4, 8, p, p, None) == INV
+    assert lib.mvae_rowsum(L.MVAE_F32, 0, 4, p, 4, p, 0, None) == INV
+    assert lib.mvae_relu_bwd(8, None, p, None) == INV
