@@ -662,13 +662,18 @@ class _DecoderFn(torch.autograd.Function):
                 nlow = min(int(os.environ.get("MVAE_DEFER_LAYERS", "2")), NL - 1)
                 layers = range(NL) if part is None else (range(nlow, NL) if part == 0 else range(nlow))
                 _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers)
-                if part == 1 and sink is not None and getattr(sink[0], "grad_sync", None) is not None:
-                    # everything from gru.weight_hh_l0 to the end of our range is final on this stream: all-reduce it now, under the
-                    # encoder's backward (weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step()).
+                if part is not None and sink is not None and getattr(sink[0], "grad_sync", None) is not None:
+                    # What this part produced is final on this stream: all-reduce it now.  Part 0 (upper layers + head: everything from
+                    # gru.weight_ih_l{nlow} to the end of our range) then travels under the SECOND group of weight-gradient GEMMs and the
+                    # encoder's backward; part 1 ([gru.weight_hh_l0, gru.weight_ih_l{nlow})) under whatever is left of the encoder's
+                    # backward.  weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step().
                     # Fork path only: there the gradients are handed over by ASSIGNMENT (p.grad = view of the flat buffer), so what
                     # step() sees is the reduced buffer; through autograd's AccumulateGrad a clone could hide it (FusedAdam.gather_grads)
-                    lo = sink[2] + offs["gru.weight_hh_l0"]
-                    sink[0].grad_sync.start_early(sink[1], lo, sink[3])
+                    first_hi = f"gru.weight_ih_l{nlow}" if nlow >= 1 else "gru.weight_hh_l0"
+                    if part == 0:
+                        sink[0].grad_sync.start_early(sink[1], sink[2] + offs[first_hi], sink[3])
+                    elif nlow >= 1:
+                        sink[0].grad_sync.start_early(sink[1], sink[2] + offs["gru.weight_hh_l0"], sink[2] + offs[first_hi])
 
         # Fork: the weight-gradient GEMMs are throughput-bound and independent of dz, while the encoder's backward that follows is a
         # latency-bound chain of small launches -> run them concurrently.  Only when our MolecularVAE peer will join the side stream
