@@ -339,11 +339,53 @@ __global__ __launch_bounds__(BMW * 2) void lstm_step_fwd_gm_kernel(StepArgsF p) 
   const StepTaskF& q = p.t[task];
   const int n0 = tm * BNB, j0 = tj * BU, H = p.H, B = p.B;
 
+  // lane -> hidden units ub .. ub + 7 (all four gates), batch rows n0 + wn * 16 NI + 16 ni + lc  (see the epilogue)
+  const int lq = lane >> 4, lc = lane & 15;
+  const int ub = j0 + 32 * wm + 8 * lq;
+  // The 256 x 256 tile STARTS its accumulators at the bias (loads in flight under the pipeline prologue; -0.1 ms / step at B = 1024, same-box
+  // A/B); the small tiles add it in the epilogue: in front of their short main loop the same loads delay the first K-step (+0.5 ms / step at b = 128).
+  constexpr bool BIAS_FIRST = (BMW == 256 && BNB == 256);
+  auto load_bias = [&](float (&bias)[4][8]) {
+    if (q.bias) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) load8<float>(q.bias + g * H + ub, bias[g]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[g][e] = 0.f;
+    }
+  };
   f32x4 acc[MI][NI];
+  if constexpr (BIAS_FIRST) {
+    float bias[4][8];
+    load_bias(bias);
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int g = 0; g < NI; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[2 * g + (e >> 2)][ni][e & 3] = bias[g][e];
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int g = 0; g < NI; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // t == 0 has no previous cell state: the loads still go out (from this cell's own output buffer: valid memory of the same shape) and the
+  // loop selects zero instead -- a branch around the loads would make the compiler wait for them at the join.  Rows past B read row B - 1.
+  float cpa[NI][8];
+  auto load_cprev_all = [&]() {
+    const float* cpsrc = q.c_prev ? q.c_prev : q.c_out;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int row = n0 + wn * (16 * NI) + ni * 16 + lc;
+      load8<float>(cpsrc + (long)(row < B ? row : B - 1) * H + ub, cpa[ni]);
+    }
+  };
+  // 256 x 256 tile: requested before the main loop as well (the kernel has the registers: 249 VGPRs; -0.1 ... -0.25 ms / step at B = 1024)
+  if constexpr (BIAS_FIRST) load_cprev_all();
 
 #ifdef MVAE_TUNING
   const bool run_main = !(p.dbg & 2);
@@ -376,46 +418,46 @@ __global__ __launch_bounds__(BMW * 2) void lstm_step_fwd_gm_kernel(StepArgsF p) 
   if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.c_out[0] = 1.f; return; }
 #endif
 
-  // ---- epilogue in registers: lane -> hidden units ub .. ub + 7, batch rows n0 + wn * 16 NI + 16 ni + c
-  const int lq = lane >> 4, lc = lane & 15;
-  const int ub = j0 + 32 * wm + 8 * lq;
-  float bias[4][8];
+  // ---- epilogue in registers.  The bias goes into the accumulators of every sub-tile first (one batch of loads under ONE uniform branch),
+  // so that its 32 registers are free again before the previous cell states of all sub-tiles are requested.  (Measured: starting the
+  // accumulators AT the bias, with its loads in front of the main loop, delays the first K-step instead: +0.7 ms / step at b = 128.)
+  if constexpr (!BIAS_FIRST) {
+    float bias[4][8];
+    load_bias(bias);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (q.bias) load8<float>(q.bias + g * H + ub, bias[g]);
-    else {
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bias[g][e] = 0.f;
-    }
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[2 * g + (e >> 2)][ni][e & 3] += bias[g][e];
   }
   T* hout = reinterpret_cast<T*>(q.h_out);
   T* gout = reinterpret_cast<T*>(q.g_out);
   T* csave = reinterpret_cast<T*>(q.c_save);
-  auto load_cprev = [&](int ni, float (&v)[8]) {
-    const int row = n0 + wn * (16 * NI) + ni * 16 + lc;
-    if (q.c_prev && row < B) load8<float>(q.c_prev + (long)row * H + ub, v);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    }
-  };
-  float cp[8], cpn[8];                          // previous cell state of sub-tile ni, and of ni + 1 (requested one sub-tile ahead)
-  load_cprev(0, cp);
+  // Previous cell state of EVERY sub-tile is requested before the first store goes out, in one batch under ONE workgroup-uniform branch:
+  // vmcnt retires loads and stores in issue order, so a load issued behind the stores of an earlier sub-tile cannot be waited for
+  // without also waiting for those stores' write acknowledgements (~2 us each time), and a per-load branch makes the compiler wait after
+  // every load.  With the loads in front the NI x 8 stores of a lane are fire-and-forget.  (Rows past B read row B - 1 and are not stored.)
+  if constexpr (!BIAS_FIRST) load_cprev_all();
+  const bool has_cprev = q.c_prev != nullptr;
+  // the layer-0 cell (time-invariant input projection q.add) is its own instantiation of the loop: the other cells' loop then has no load
+  // in it at all, and no wait between one sub-tile's stores and the next sub-tile's math
+  // ... and so is the workgroup whose batch tile lies entirely inside the batch (no per-lane row test, hence no exec-mask branches
+  // between the sub-tiles for the wait-count pass to be conservative about)
+  auto epilogue = [&](auto has_add, auto full_tile) {
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int row = n0 + wn * (16 * NI) + ni * 16 + lc;
-    if (ni + 1 < NI) load_cprev(ni + 1, cpn);
-    if (row >= B) {
+    if constexpr (!decltype(full_tile)::value) { if (row >= B) continue; }
+    float cp[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) cp[e] = cpn[e];
-      continue;
-    }
+    for (int e = 0; e < 8; ++e) cp[e] = has_cprev ? cpa[ni][e] : 0.f;
     float pre[4][8];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pre[g][e] = acc[2 * g + (e >> 2)][ni][e & 3] + bias[g][e];
-    if (q.add) {
+      for (int e = 0; e < 8; ++e) pre[g][e] = acc[2 * g + (e >> 2)][ni][e & 3];
+    if constexpr (decltype(has_add)::value) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float a[8];
@@ -431,16 +473,27 @@ __global__ __launch_bounds__(BMW * 2) void lstm_step_fwd_gm_kernel(StepArgsF p) 
       c[e] = gf[e] * cp[e] + gi[e] * gg[e];
       h[e] = go[e] * act_tanh<T>(c[e]);
     }
-    store8<float>(q.c_out + (long)row * H + ub, c);
-    store8<T>(hout + (long)row * q.ldh + ub, h);
+#ifdef MVAE_TUNING
+    // diagnostic builds only (results wrong): bit 2 = every store of the tile goes to its first 16 rows (same instructions, 1/16 of the
+    // HBM write footprint: separates store ISSUE cost from write bandwidth), bit 3 = the saved gates are not stored (half the bytes)
+    const int srow = (p.dbg & 4) ? n0 + (row & 15) : row;
+    const bool sgate = !(p.dbg & 8);
+#else
+    const int srow = row;
+    constexpr bool sgate = true;
+#endif
+    store8<float>(q.c_out + (long)srow * H + ub, c);
+    store8<T>(hout + (long)srow * q.ldh + ub, h);
     if (gout) {
-      T* g4 = gout + (long)row * 4 * H + ub;
-      store8<T>(csave + (long)row * H + ub, c);
-      store8<T>(g4, gi); store8<T>(g4 + H, gf); store8<T>(g4 + 2 * H, gg); store8<T>(g4 + 3 * H, go);
+      T* g4 = gout + (long)srow * 4 * H + ub;
+      store8<T>(csave + (long)srow * H + ub, c);
+      if (sgate) { store8<T>(g4, gi); store8<T>(g4 + H, gf); store8<T>(g4 + 2 * H, gg); store8<T>(g4 + 3 * H, go); }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cp[e] = cpn[e];
   }
+  };
+  const bool full = n0 + BNB <= B;
+  if (q.add) { if (full) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::true_type{}, std::false_type{}); }
+  else { if (full) epilogue(std::false_type{}, std::true_type{}); else epilogue(std::false_type{}, std::false_type{}); }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
