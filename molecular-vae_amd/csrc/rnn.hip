@@ -184,7 +184,36 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
   const int j8 = j0 + g8 * 8;
   const int n = (H - j8 < 8) ? (H - j8) : 8;   // <= 0: this thread's units are outside the layer
   const bool vec = p.vec != 0;
+  // FAST = vector path, whole 8-unit groups, batch tile entirely inside the batch: straight-line loads and stores.  Every `if (ptr) load`
+  // (and every ldn / stn with its own vec test) is a branch, and at each join the compiler waits for all loads in flight -- four dependent
+  // round trips for the bias and one per row for the previous state; in the fast form they all go out together: an absent bias is read
+  // from c_out (valid fp32 memory, at least 4H long) and replaced by zero, the state loads sit under ONE uniform branch.
+  const bool fast = vec && n == 8 && m0 + BM <= B && (BM * GPRW) % NTHR == 0;
   float bias[4][8], cpv[NIT][8];
+  if (fast) {
+    const float* bsrc = q.bias ? q.bias : q.c_out;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load8<float>(bsrc + g * H + j8, bias[g]);
+    if (q.c_prev) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) load8<float>(q.c_prev + (long)(m0 + tid / GPRW + it * (NTHR / GPRW)) * H + j8, cpv[it]);
+    } else if (q.hprev_t0) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        load8<T>(reinterpret_cast<const T*>(q.hprev_t0) + (long)(m0 + tid / GPRW + it * (NTHR / GPRW)) * q.lda1 + j8, cpv[it]);
+    } else {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cpv[it][e] = 0.f;
+    }
+    if (!q.bias) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[g][e] = 0.f;
+    }
+  } else {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     if (q.bias && n > 0) ldn<float>(q.bias + g * H + j8, bias[g], n, vec);
@@ -205,6 +234,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
       for (int e = 0; e < 8; ++e) cpv[it][e] = 0.f;
     }
   }
+  }
   if (!WS || tid < 256) {
     const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
@@ -222,11 +252,18 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
   T* hout = reinterpret_cast<T*>(q.h_out);
   T* gout = reinterpret_cast<T*>(q.g_out);
   T* csave = reinterpret_cast<T*>(q.c_save);
+  // the loop over the thread's rows, instantiated for (fast, has an addend): in the fast form without an addend -- every cell but layer 0 --
+  // there is no load in the loop at all, so no wait between one row's stores and the next row's math
+  auto rows = [&](auto fast_tag, auto add_tag) {
+  constexpr bool FAST = decltype(fast_tag)::value, HAS_ADD = decltype(add_tag)::value;
+  auto ld32 = [&](const float* src, float (&v)[8]) { if constexpr (FAST) load8<float>(src, v); else ldn<float>(src, v, n, vec); };
+  auto st32 = [&](float* dst, const float (&v)[8]) { if constexpr (FAST) store8<float>(dst, v); else stn<float>(dst, v, n, vec); };
+  auto stT = [&](T* dst, const float (&v)[8]) { if constexpr (FAST) store8<T>(dst, v); else stn<T>(dst, v, n, vec); };
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int lrow = tid / GPRW + it * (NTHR / GPRW);
     const int row = m0 + lrow;
-    if (lrow >= BM || row >= B) continue;
+    if constexpr (!FAST) { if (lrow >= BM || row >= B) continue; }
     float pre[4][8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -235,6 +272,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
       pre[g][0] = a.x + bias[g][0]; pre[g][1] = a.y + bias[g][1]; pre[g][2] = a.z + bias[g][2]; pre[g][3] = a.w + bias[g][3];
       pre[g][4] = b.x + bias[g][4]; pre[g][5] = b.y + bias[g][5]; pre[g][6] = b.z + bias[g][6]; pre[g][7] = b.w + bias[g][7];
     }
+    if constexpr (HAS_ADD) {
     if (q.add_tbl) {        // token table (a few hundred KB, L2-resident): the [T, B, 4H] gathered copy is never materialised
       long id = q.add_idx[(long)row * q.add_idx_ld];
       id = id < 0 ? 0 : (id >= q.add_rows ? q.add_rows - 1 : id);
@@ -242,9 +280,9 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float a[8], b[8];
-        ldn<float>(tr + g * H, a, n, vec);
+        ld32(tr + g * H, a);
         if (q.add) {        // (table row + per-sequence addend) first, as mvae_gather_rows_tb forms it: same bits as the gathered path
-          ldn<float>(q.add + (long)row * q.add_ld + g * H + j8, b, n, vec);
+          ld32(q.add + (long)row * q.add_ld + g * H + j8, b);
 #pragma unroll
           for (int e = 0; e < 8; ++e) a[e] += b[e];
         }
@@ -255,10 +293,11 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float a[8];
-        ldn<float>(q.add + (long)row * q.add_ld + g * H + j8, a, n, vec);
+        ld32(q.add + (long)row * q.add_ld + g * H + j8, a);
 #pragma unroll
         for (int e = 0; e < 8; ++e) pre[g][e] += a[e];
       }
+    }
     }
     const float (&cp)[8] = cpv[it];
     T* g4 = gout + (long)row * 4 * H + j8;
@@ -270,17 +309,17 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
         c[e] = gf[e] * cp[e] + gi[e] * gg[e];
         h[e] = go[e] * act_tanh<T>(c[e]);
       }
-      stn<float>(q.c_out + (long)row * H + j8, c, n, vec);
-      stn<T>(hout + (long)row * q.ldh + j8, h, n, vec);
+      st32(q.c_out + (long)row * H + j8, c);
+      stT(hout + (long)row * q.ldh + j8, h);
       if (q.h_drop) {
         float hd[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) hd[e] = (e < n) ? h[e] * drop_factor(p.drop, q.dmask, q.didx0, (long)row * H + j8 + e) : 0.f;
-        stn<T>(reinterpret_cast<T*>(q.h_drop) + (long)row * q.ldh + j8, hd, n, vec);
+        stT(reinterpret_cast<T*>(q.h_drop) + (long)row * q.ldh + j8, hd);
       }
       if (gout) {           // forward-only passes (no_grad) hand in no save buffers: 12 of the 16 bytes per (row, unit) are not written
-        stn<T>(csave + (long)row * H + j8, c, n, vec);
-        stn<T>(g4, gi, n, vec); stn<T>(g4 + H, gf, n, vec); stn<T>(g4 + 2 * H, gg, n, vec); stn<T>(g4 + 3 * H, go, n, vec);
+        stT(csave + (long)row * H + j8, c);
+        stT(g4, gi); stT(g4 + H, gf); stT(g4 + 2 * H, gg); stT(g4 + 3 * H, go);
       }
     } else {
       // GRU (torch.nn.GRU): slots = [r | z | W_in x + b_in | W_hn h + b_hn];  cp = h_{t-1} (fp32 recurrent state)
@@ -294,17 +333,21 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
         hs_[e] = valid ? hn : cp[e];          // a finished sequence keeps its last state (pack_sequence semantics) ...
         hseq[e] = valid ? hn : 0.f;           // ... and emits zeros (pad_packed_sequence)
       }
-      stn<float>(q.c_out + (long)row * H + j8, hs_, n, vec);
-      stn<T>(hout + (long)row * q.ldh + j8, hseq, n, vec);
+      st32(q.c_out + (long)row * H + j8, hs_);
+      stT(hout + (long)row * q.ldh + j8, hseq);
       if (q.h_drop) {
         float hd[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) hd[e] = (e < n) ? hseq[e] * drop_factor(p.drop, q.dmask, q.didx0, (long)row * H + j8 + e) : 0.f;
-        stn<T>(reinterpret_cast<T*>(q.h_drop) + (long)row * q.ldh + j8, hd, n, vec);
+        stT(reinterpret_cast<T*>(q.h_drop) + (long)row * q.ldh + j8, hd);
       }
-      if (gout) { stn<T>(g4, gr, n, vec); stn<T>(g4 + H, gz, n, vec); stn<T>(g4 + 2 * H, gn, n, vec); stn<T>(g4 + 3 * H, pre[3], n, vec); }
+      if (gout) { stT(g4, gr); stT(g4 + H, gz); stT(g4 + 2 * H, gn); stT(g4 + 3 * H, pre[3]); }
     }
   }
+  };
+  const bool has_add = q.add != nullptr || q.add_tbl != nullptr;
+  if (fast) { if (has_add) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+  else { if (has_add) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
 }
 
 // ---------------------------------------------------------------------------------------------- forward, gate-major tile
@@ -514,7 +557,8 @@ struct StepTaskB {
 };
 struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split, gru3; DropArgs drop; };
 
-// Gate-derivative math of one (batch row, 8 hidden units) group, given dh = sum of the two contractions (fp32).
+// Gate-derivative math of one (batch row, 8 hidden units) group, given dh = sum of the two contractions (fp32): the general form (any n,
+// scalar or vector accesses, operands requested where they are used).  The element-wise launch of the split forms and ragged tiles use it.
 template <typename T>
 __device__ __forceinline__ void bwd_cell_group(const StepArgsB& p, const StepTaskB& q, int row, int j8, int n, bool vec, float (&dh)[8]) {
   const int H = p.H;
@@ -605,9 +649,122 @@ __device__ __forceinline__ void bwd_cell_group(const StepArgsB& p, const StepTas
   }
 }
 
+// The same math in two phases for the fused kernel's whole tiles:
+//   bwd_cell_load    requests everything the group reads from global memory (saved gates, cell states / h_{t-1}, the carried gradient, dy),
+//   bwd_cell_finish  does the math and stores dG and the carried gradient,
+// so that a caller can put the loads of its NEXT group in front of the stores of the current one: vmcnt retires loads and stores in issue
+// order, and a load issued behind a store cannot be waited for without waiting for that store's write acknowledgement.
+// FAST (vector path, whole 8-unit groups: what the host guarantees whenever H % 8 == 0 and everything is 16-byte aligned) is straight-line:
+// every load goes out unconditionally -- an absent operand (no carried gradient at t = T-1, no dy below the top layer, no c_{t-1} at
+// t = 0) is read from a buffer of the same shape that the kernel owns anyway and replaced by zero in bwd_cell_finish -- because each
+// `if (ptr) load` is a branch, and at every join the compiler waits for all loads in flight: ten dependent round trips per group.
+struct BwdOps { float dci[8], dy[8], g[4][8], c[8], cp[8]; };      // GRU: g = r, z, n, W_hn h + b_hn; cp = h_{t-1}; c unused
+
+template <typename T, bool FAST>
+__device__ __forceinline__ void bwd_cell_load(const StepArgsB& p, const StepTaskB& q, int row, int j8, int n, bool vec, BwdOps& r) {
+  const int H = p.H;
+  const T* gates = reinterpret_cast<const T*>(q.gates);
+  const long o = (long)row * H + j8;
+  if constexpr (FAST) {
+    load8<float>((q.dc_in ? q.dc_in : q.dc_out) + o, r.dci);
+    if (gates == nullptr) return;                   // GRU pseudo-cell t = -1 (workgroup-uniform): only the carry is read
+    load8<float>(q.dy ? q.dy + (long)row * q.dy_ld + j8 : q.dc_out + o, r.dy);
+    const T* g4 = gates + (long)row * 4 * H + j8;
+    load8<T>(g4, r.g[0]); load8<T>(g4 + H, r.g[1]); load8<T>(g4 + 2 * H, r.g[2]); load8<T>(g4 + 3 * H, r.g[3]);
+    if (p.cell == MVAE_CELL_LSTM) {
+      const T* cs = reinterpret_cast<const T*>(q.c);
+      const T* csp = reinterpret_cast<const T*>(q.c_prev);
+      load8<T>(cs + o, r.c);
+      load8<T>((csp ? csp : cs) + o, r.cp);
+    } else {
+      load8<T>(q.h_prev ? reinterpret_cast<const T*>(q.h_prev) + (long)row * q.ldhp + j8 : g4, r.cp);
+    }
+  } else {
+    if (q.dc_in) ldn<float>(q.dc_in + o, r.dci, n, vec);
+    if (gates == nullptr) return;
+    if (q.dy) ldn<float>(q.dy + (long)row * q.dy_ld + j8, r.dy, n, vec);
+    const T* g4 = gates + (long)row * 4 * H + j8;
+    ldn<T>(g4, r.g[0], n, vec); ldn<T>(g4 + H, r.g[1], n, vec); ldn<T>(g4 + 2 * H, r.g[2], n, vec); ldn<T>(g4 + 3 * H, r.g[3], n, vec);
+    if (p.cell == MVAE_CELL_LSTM) {
+      ldn<T>(reinterpret_cast<const T*>(q.c) + o, r.c, n, vec);
+      if (q.c_prev) ldn<T>(reinterpret_cast<const T*>(q.c_prev) + o, r.cp, n, vec);
+    } else if (q.h_prev) ldn<T>(reinterpret_cast<const T*>(q.h_prev) + (long)row * q.ldhp + j8, r.cp, n, vec);
+  }
+}
+
+template <typename T, bool FAST>
+__device__ __forceinline__ void bwd_cell_finish(const StepArgsB& p, const StepTaskB& q, int row, int j8, int n, bool vec, const BwdOps& r,
+                                                float (&dh)[8]) {
+  const int H = p.H;
+  T* dG = reinterpret_cast<T*>(q.dG);
+  const long o = (long)row * H + j8;
+  auto st32 = [&](float* dst, const float (&v)[8]) { if constexpr (FAST) store8<float>(dst, v); else stn<float>(dst, v, n, vec); };
+  auto stT = [&](T* dst, const float (&v)[8]) { if constexpr (FAST) store8<T>(dst, v); else stn<T>(dst, v, n, vec); };
+  const bool has_dci = q.dc_in != nullptr, has_dy = q.dy != nullptr;
+  float dci[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dci[e] = has_dci ? r.dci[e] : 0.f;
+  if (p.cell == MVAE_CELL_LSTM) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dh[e] += has_dy ? r.dy[e] : 0.f;
+    const bool has_cp = q.c_prev != nullptr;
+    float di[8], df[8], dg[8], dO[8], dco[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gi = r.g[0][e], gf = r.g[1][e], gg = r.g[2][e], go = r.g[3][e], cp = has_cp ? r.cp[e] : 0.f;
+      const float tc = act_tanh<T>(r.c[e]);
+      const float d_o = dh[e] * tc;
+      const float dc = dh[e] * go * (1.f - tc * tc) + dci[e];
+      dco[e] = dc * gf;
+      di[e] = dc * gg * gi * (1.f - gi);
+      df[e] = dc * cp * gf * (1.f - gf);
+      dg[e] = dc * gi * (1.f - gg * gg);
+      dO[e] = d_o * go * (1.f - go);
+    }
+    st32(q.dc_out + o, dco);
+    T* d4 = dG + (long)row * q.ldg + j8;
+    stT(d4, di); stT(d4 + H, df); stT(d4 + 2 * H, dg); stT(d4 + 3 * H, dO);
+  } else {
+    // GRU.  dh so far = dG^l_{t+1}[r,z,.,n*r] . W_hh + dG^{l+1}_t[r,z,n,.] . W_ih ; dci = the element-wise carry dh_{t+1} * z_{t+1}
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dh[e] += dci[e];
+    if (q.gates == nullptr) {                       // pseudo-cell t = -1: gradient w.r.t. the initial hidden state
+      st32(q.dh0 + o, dh);
+      return;
+    }
+    const bool valid = p.lengths ? (q.t < p.lengths[row]) : true;
+    const bool has_hp = q.h_prev != nullptr;
+    float dpr[8], dpz[8], dpn[8], dpnr[8], carry[8];
+    if (valid) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dh[e] += has_dy ? r.dy[e] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gr = r.g[0][e], gz = r.g[1][e], gn = r.g[2][e], nh = r.g[3][e], hp = has_hp ? r.cp[e] : 0.f;
+        const float dn = dh[e] * (1.f - gz);
+        const float dz = dh[e] * (hp - gn);
+        dpn[e] = dn * (1.f - gn * gn);
+        dpr[e] = dpn[e] * nh * gr * (1.f - gr);
+        dpz[e] = dz * gz * (1.f - gz);
+        dpnr[e] = dpn[e] * gr;
+        carry[e] = dh[e] * gz;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dpr[e] = 0.f; dpz[e] = 0.f; dpn[e] = 0.f; dpnr[e] = 0.f; carry[e] = dh[e]; }
+    }
+    st32(q.dc_out + o, carry);
+    T* d4 = dG + (long)row * q.ldg + j8;
+    stT(d4, dpr); stT(d4 + H, dpz); stT(d4 + 2 * H, dpn); stT(d4 + 3 * H, dpnr);
+  }
+}
+
 // DROP: instantiations that can apply the inter-layer dropout factor inside the fused (single-launch) form -- a separate template
 // flag so that the hot instantiations carry no trace of it (with both forms in one body hipcc moved the LDS-DMA descriptors to scratch).
-template <typename T, int BM, int BN, int NBUF, bool WS = false, bool DROP = false>
+// SPLITMODE: 1 = instantiation launched in split mode only (stores partial tiles; carries no gate-derivative epilogue), 0 = fused only
+// (no partial-tile code), -1 = decided at run time.  The step kernels of the small batches run ~20 us: what an instantiation does not
+// need is kept out of its code (the same kernel with both epilogues in it: +0.8 us per launch at b = 128).
+template <typename T, int BM, int BN, int NBUF, bool WS = false, bool DROP = false, int SPLITMODE = -1>
 __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB p) {
   constexpr bool PIPE = NBUF > 0;
   constexpr int NTHR = WS ? 512 : 256;
@@ -753,7 +910,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
   if (j8 >= H) return;
   const int n = (H - j8 < 8) ? (H - j8) : 8;
   const bool vec = p.vec != 0;
-  if (p.split) {
+  if ((SPLITMODE == 1) || (SPLITMODE == -1 && p.split)) {
     // split mode (host guarantees whole tiles and the vector path): store this segment's fp32 partial tile; lstm_bwd_epi_kernel sums
     float* part = p.partial + ((long)(task * nsp + sp) * B) * H;
 #pragma unroll
@@ -768,18 +925,37 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
     }
     return;
   }
+  if constexpr (SPLITMODE != 1) {
+  constexpr int NIT = (BM * GPR + NTHR - 1) / NTHR;
+  auto read_dh = [&](int lrow, float (&dh)[8]) {
+    const float* s = stg + lrow * SN + g8 * 8;
+    const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+    dh[0] = a.x; dh[1] = a.y; dh[2] = a.z; dh[3] = a.w; dh[4] = b.x; dh[5] = b.y; dh[6] = b.z; dh[7] = b.w;
+  };
+  // whole tile inside the batch, vector path, whole groups: the straight-line form, software-pipelined by one group -- the operands of
+  // group it + 1 are requested before the stores of group it go out (bwd_cell_load / bwd_cell_finish)
+  if (vec && n == 8 && m0 + BM <= B && (BM * GPR) % NTHR == 0) {
+    BwdOps ops[2];
+    bwd_cell_load<T, true>(p, q, m0 + tid / GPR, j8, 8, true, ops[0]);
 #pragma unroll
-  for (int it = 0; it < (BM * GPR + NTHR - 1) / NTHR; ++it) {
+    for (int it = 0; it < NIT; ++it) {
+      const int lrow = tid / GPR + it * (NTHR / GPR);
+      if (it + 1 < NIT) bwd_cell_load<T, true>(p, q, m0 + lrow + NTHR / GPR, j8, 8, true, ops[(it + 1) & 1]);
+      float dh[8];
+      read_dh(lrow, dh);
+      bwd_cell_finish<T, true>(p, q, m0 + lrow, j8, 8, true, ops[it & 1], dh);
+    }
+    return;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
     const int lrow = tid / GPR + it * (NTHR / GPR);
     const int row = m0 + lrow;
     if (lrow >= BM || row >= B) continue;
     float dh[8];
-    {
-      const float* s = stg + lrow * SN + g8 * 8;
-      const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
-      dh[0] = a.x; dh[1] = a.y; dh[2] = a.z; dh[3] = a.w; dh[4] = b.x; dh[5] = b.y; dh[6] = b.z; dh[7] = b.w;
-    }
+    read_dh(lrow, dh);
     bwd_cell_group<T>(p, q, row, j8, n, vec, dh);
+  }
   }
 }
 
@@ -808,6 +984,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_epi_kernel(StepArgsB p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dh[e] += a[e];
   }
+  // One group per thread: the conditional form (operands requested one after the other, few registers, eight waves per SIMD to hide
+  // it) is the faster one here -- the straight-line form costs 134 VGPRs = three waves per SIMD: 53.1 vs 50.7 us per launch pair at B = 512.
   bwd_cell_group<T>(p, q, row, j8, 8, true, dh);
 }
 
@@ -933,7 +1111,6 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   a.dbg = 0;
 #endif
   const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (BJ == 64) ? 3 : (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
-  const bool ws = tune_int("MVAE_WS_FWD", 1) != 0;      // loader / consumer wave specialisation for the wide tile
   size_t lds = (size_t)(nbuf > 0 ? nbuf : 2) * (BM + 4 * BJ) * KB;
   const size_t stage_bytes = (size_t)BM * 4 * (BJ + 4) * sizeof(float);     // epilogue staging tile
   if (lds < stage_bytes) lds = stage_bytes;
@@ -991,8 +1168,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     }
 #define FWD_CASE(TT_, BM_, NB_) if (BJ == 32 && BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
     if (BJ == 64 && nbuf == 3) {
-      if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3, true>)); }
-      else MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3>));
+      block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<bf16_t, 128, 64, 3, true>));      // loader / consumer wave specialisation
       continue;
     }
     if (dt == MVAE_BF16) {
@@ -1146,12 +1322,12 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n * (split ? nsplit : 1)), block(256);
-    if (big_fused) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true>)); continue; }
+    if (big_fused) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0>)); continue; }
     if (split) {
-      if (BM == 256) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 256, 128, 3, true>)); block = dim3(256); }
-      else if (BN == 64) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true>)); block = dim3(256); }
-      else if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true>)); block = dim3(256); }
-      else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4>));
+      if (BM == 256) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 256, 128, 3, true, false, 1>)); block = dim3(256); }
+      else if (BN == 64) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true, false, 1>)); block = dim3(256); }
+      else if (ws) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 1>)); block = dim3(256); }
+      else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, false, false, 1>));
       const long groups = (long)n * B * (H / 8);
       hipLaunchKernelGGL((lstm_bwd_epi_kernel<bf16_t>), dim3((unsigned)((groups + 255) / 256)), block, 0, st, a);
       continue;
