@@ -80,6 +80,10 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
       W[g][kk] = v;
     }
   }
+  // The weight registers are complete BEFORE the time loop is entered.  Without this the wait-count pass sees them as possibly still in
+  // flight at the loop header (pending on the entry edge, complete on the back edge) and puts vmcnt(0) in front of the first MFMA of
+  // EVERY step -- which also drains the prefetch loads issued a few instructions earlier and the previous step's stores.
+  __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0), expcnt / lgkmcnt untouched
   // ---- per-thread items of the gate phase: (row, unit) = (id / H, id % H), id = tid (+ 256)
   constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + NTHR - 1) / NTHR;
   float c_prev[NIT], bia[NIT][4], addv[NIT][4];
@@ -133,7 +137,9 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
         for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     }
     __syncthreads();
-    // ---- gate phase
+    // ---- gate phase.  x_{t+1} (requested before the MFMA phase) goes into the next A buffer first: behind this step's stores the wait
+    // for it would also wait for their write acknowledgements
+    if (HASX && tid < RR_ROWS * (H / 4)) *reinterpret_cast<float4*>(&abuf[nxt][xr][xc]) = xpre;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = tid + it * NTHR, row = id / H, u = id % H;
@@ -157,7 +163,6 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
         g4[0] = gi; g4[H] = gf; g4[2 * H] = gg; g4[3 * H] = go;
       }
     }
-    if (HASX && tid < RR_ROWS * (H / 4)) *reinterpret_cast<float4*>(&abuf[nxt][xr][xc]) = xpre;
     if (p.add && t + 1 < T) load_add(t + 1);
     __syncthreads();
   }
@@ -203,6 +208,7 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, bool HASX, fl
       W[g][kk] = v;
     }
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);           // weight registers complete before the loop (see the forward kernel)
   constexpr int NITEM = RR_ROWS * H, NIT = (NITEM + NTHR - 1) / NTHR;
   float dc_carry[NIT], c_cur[NIT], c_prev[NIT], gt[NIT][4], dyv[NIT];
   auto prefetch = [&](int t) {       // gates[t], c[t-1], dy[t]

@@ -84,7 +84,8 @@ for r in range(args.rounds):
         tag = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in prof.items()}
         res[i].append(dt)
         print(f"round {r} {s}: {dt:.3f} ms/step  fwd {tag.get('dec_lstm_fwd', 0):.3f} bwd {tag.get('dec_lstm_bwd', 0):.3f} "
-              f"wgrad {tag.get('dec_lstm_wgrad', 0):.3f}+{tag.get('dec_lstm_wgrad_deferred', 0):.3f}", flush=True)
+              f"wgrad {tag.get('dec_lstm_wgrad', 0):.3f}+{tag.get('dec_lstm_wgrad_deferred', 0):.3f} "
+              f"enc {tag.get('enc_lstm_fwd', 0):.3f}/{tag.get('enc_lstm_bwd', 0):.3f}", flush=True)
 for i, s in enumerate(settings):
     v = sorted(res[i])
     print(f"{s}: median {v[len(v) // 2]:.3f} min {v[0]:.3f} ms/step")

@@ -7,7 +7,7 @@ for b in $BATCHES; do
   for r in $(seq $R); do
     for lib in $A $B; do
       echo -n "B=$b $(basename $lib): "
-      MVAE_LIB=$(pwd)/$lib timeout -k 10 300 python3 tests/ab_step.py --batch $b --rounds 2 --steps 10 2>&1 | tail -1
+      MVAE_LIB=$(pwd)/$lib timeout -k 10 300 python3 tests/ab_step.py --batch $b --rounds 2 --steps 10 2>&1 | tail -2 | tr '\n' ' '; echo
     done
   done
 done
