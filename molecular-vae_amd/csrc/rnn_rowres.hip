@@ -186,11 +186,12 @@ struct RowResBAll { RowResB l[MVAE_MAX_LAYERS]; int nl; };
 // workgroup only ever reads the dx rows it wrote itself, so an agent-scope fence + barrier between layers is all the ordering needed.
 // One launch keeps the 128 workgroups resident for the whole pass: they do not have to win their CUs back from concurrently
 // running GEMM workgroups at every layer boundary.  Layer 0 has no input gradient (hasx = false: zero W_ih fragments, no dx stores).
-template <int H, int NTHR>
-__device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, bool HASX, float (&gbuf)[RR_ROWS][4 * H + 24], float (&red)[4][RR_ROWS][192]) {
-  constexpr int G4 = 4 * H, KW = H, NOUT = 2 * H, NG = (NOUT + 63) / 64, NA = (KW + 15) / 16;
-  constexpr int GPAD = G4 + 24, NPAD = NG * 64, RO = H;                  // RO: column of dh_rec inside the MFMA output
-  static_assert((GPAD % 32) == 24 && NPAD == 192, "A-buffer rows on disjoint banks");
+// HASX = false (layer 0: no input gradient): the MFMA output is dh_rec alone -- H columns = 2 groups of 64 instead of 3, a third fewer MFMAs.
+template <int H, int NTHR, bool HASX>
+__device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)[RR_ROWS][4 * H + 24], float (&red)[4][RR_ROWS][192]) {
+  constexpr int G4 = 4 * H, KW = H, NOUT = HASX ? 2 * H : H, NG = (NOUT + 63) / 64, NA = (KW + 15) / 16;
+  constexpr int GPAD = G4 + 24, NPAD = NG * 64, RO = HASX ? H : 0;       // RO: column of dh_rec inside the MFMA output
+  static_assert((GPAD % 32) == 24 && NPAD <= 192, "A-buffer rows on disjoint banks");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * RR_ROWS, B = p.B, T = p.T;
   float W[NG][KW];
@@ -202,7 +203,7 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, bool HASX, fl
       const int k = KW * (wave & 3) + kk;
       float v = 0.f;
       if (n < NOUT && wave < 4) {
-        if (n < H) v = HASX ? p.w_ihT[(long)n * p.ldw_ihT + k] : 0.f;
+        if (HASX && n < H) v = p.w_ihT[(long)n * p.ldw_ihT + k];
         else v = p.w_hhT[(long)(n - RO) * p.ldw_hhT + k];
       }
       W[g][kk] = v;
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) 
   __shared__ float gbuf[RR_ROWS][4 * H + 24];         // dG_t of the 4 rows (A operand)
   __shared__ float red[4][RR_ROWS][192];
   for (int l = a.nl - 1; l >= 0; --l) {
-    rowres_bwd_layer<H, 256>(a.l[l], l > 0, gbuf, red);
+    if (l > 0) rowres_bwd_layer<H, 256, true>(a.l[l], gbuf, red);
+    else rowres_bwd_layer<H, 256, false>(a.l[l], gbuf, red);
     if (l > 0) { __threadfence(); __syncthreads(); }  // our dx rows are visible to the loads of the next layer; gbuf / red are free again
   }
 }
