@@ -213,6 +213,16 @@ def test_lstm_wavefront_fwd_bwd_vs_oracle(case):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("hoist", ["0", "1"])
+def test_row_resident_lstm_with_and_without_hoisted_input_projection(hoist, monkeypatch):
+    """The encoder's row-resident schedule (H = 72, f32) in both of its forms: upper layers contracting [x_t | h_{t-1}] per step (what
+    large batches take) and with x . W_ih^T for all t hoisted into one GEMM written in place into the saved-gates buffer (small T * B)."""
+    monkeypatch.setenv("MVAE_ROWRES_HOIST", hoist)
+    errs = _lstm_case(torch.float32, 6, 37, 72, 3, 8)
+    bad = {k: v for k, v in errs.items() if v > 2e-5}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("env", [{"MVAE_BJ": "64"}, {"MVAE_BM": "128", "MVAE_NBUF_FWD": "4", "MVAE_NBUF_BWD": "5"},
                                  {"MVAE_BM": "64", "MVAE_BJ": "32", "MVAE_NBUF_FWD": "5", "MVAE_NBUF_BWD": "3"}])
 def test_lstm_tile_variants_vs_oracle(env, monkeypatch):
