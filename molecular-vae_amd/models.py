@@ -720,9 +720,21 @@ class MolecularVAE(nn.Module):
         self.encoder = MolEncoder(i=i, o=o, c=c)
         self.decoder = MolDecoder(i=o, o=i, c=c, dtype=dtype)
         self.decoder.__dict__["_peer"] = weakref.ref(self.encoder)
+        self.prepack_decoder = True       # refresh the decoder's weight shadows on the side stream beside the encoder's forward
 
     def forward(self, x, eps=None):
+        ev = None
+        if x.is_cuda and self.prepack_decoder and os.environ.get("MVAE_PREPACK", "1") != "0":
+            # the decoder's weight shadows (8 bf16 cast / transposes of 4096 x 1024) are independent of the encoder's forward: refresh them
+            # on the side stream beside it (after everything issued so far: the optimiser update they read)
+            side = self.decoder._side_stream(x.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.decoder._pack(x.device)
+                ev = torch.cuda.Event(); ev.record()
         x, mu, logvar = self.encoder(x, eps) if eps is not None else self.encoder(x)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         self.decoder.__dict__["_z_from_peer"] = True       # this forward's z comes from our encoder: its backward will join / release side work
         try:
             return self.decoder(x), mu, logvar
