@@ -197,6 +197,7 @@ def test_gemm_tn_bf16_tile_variants(shape, bm, monkeypatch):
 
 @pytest.mark.parametrize("case", [
     (torch.float32, 7, 5, 32, 2, 16, 2e-5),       # tiny, generic register-staged path
+    (torch.float32, 4, 6, 20, 2, 8, 2e-5),        # H not a multiple of 8: element-wise (non-vector) epilogues, partial 8-unit groups
     (torch.bfloat16, 7, 5, 32, 2, 16, 3e-2),
     (torch.float32, 5, 70, 72, 3, 8, 2e-5),       # encoder-like H=72, 3 layers: the row-resident schedule (4 rows per workgroup, ragged last one)
     (torch.float32, 1, 6, 72, 1, 8, 2e-5),        # row-resident edge cases: T = 1, single layer (no input gradient)
