@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 3
+#define MVAE_ABI_VERSION 4
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -186,6 +186,11 @@ int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
  * and, in the epilogue, the gate derivative dG^{l}_t (pre-activation gradient) and dc_{t-1}.
  *   w_hhT[l] [H, G*H], w_ihT[l] [in, G*H]: TRANSPOSED weights (K-contiguous for this contraction).
  *   dy       [T][B][H] fp32 gradient w.r.t. the stack output (row stride dy_ld).
+ *   dy_a / dy_w / dy_k (optional, LSTM, dtype bf16): the same gradient given as a product  dy_t = dy_a[t] . dy_w^T  with
+ *            dy_a [T][B][dy_a_ld] dtype (e.g. the logit gradients of TimeDistributed(Linear), models.py:157) and dy_w [H][dy_w_ld] dtype
+ *            (the Linear's weight, transposed), both zero-padded to dy_k columns, dy_k a multiple of 128: the TOP layer's cell contracts it
+ *            as its second K-segment (that cell has no layer above), so the [T, B, H] fp32 tensor is never written or read.
+ *            dy and dy_a may both be given (they add).
  *   dG[l]    [T][B][ldg]  dtype  (out)  pre-activation gradients (G*H valid columns); dG[0] is also the gradient of add0.
  *   dstate[l] [2][B][H] fp32 scratch (ping-pong dc).
  * Weight / bias / input gradients are then mvae_gemm_tn(dG[l], hs[l-1] / hs[l] shifted by one step) and mvae_colsum_t(dG[l]).
@@ -196,6 +201,7 @@ typedef struct {
   const void* w_ihT[MVAE_MAX_LAYERS]; int64_t ldw_ihT[MVAE_MAX_LAYERS];   /* w_ihT[0] unused */
   const int32_t* lengths;
   const float* dy; int64_t dy_ld;
+  const void* dy_a; int64_t dy_a_ld; const void* dy_w; int64_t dy_w_ld; int dy_k;   /* optional (NULL): see above */
   const float* dh_last[MVAE_MAX_LAYERS];                                  /* optional fp32 [B,H] gradient w.r.t. the final hidden state */
   const void* hs[MVAE_MAX_LAYERS]; int64_t ldh;
   const void* h0[MVAE_MAX_LAYERS]; int64_t ldh0;

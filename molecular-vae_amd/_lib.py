@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # run with any MVAE_* variable set, so a measured number always comes from the product library.
 LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MVAE_F32, MVAE_BF16 = 0, 1
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
 CELL_LSTM, CELL_GRU = 0, 1
@@ -45,6 +45,7 @@ class RnnBwdDesc(C.Structure):
                 ("w_ihT", _vp * MAX_LAYERS), ("ldw_ihT", _i64 * MAX_LAYERS),
                 ("lengths", _vp),
                 ("dy", _vp), ("dy_ld", _i64),
+                ("dy_a", _vp), ("dy_a_ld", _i64), ("dy_w", _vp), ("dy_w_ld", _i64), ("dy_k", _i),
                 ("dh_last", _vp * MAX_LAYERS),
                 ("hs", _vp * MAX_LAYERS), ("ldh", _i64),
                 ("h0", _vp * MAX_LAYERS), ("ldh0", _i64),

@@ -1202,7 +1202,10 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   const int NL = d->layers, T = d->T, B = d->B, H = d->H, dt = d->dtype;
   const int epc = (dt == MVAE_BF16) ? 8 : 4;
   const bool gru = d->cell == MVAE_CELL_GRU;
-  if (!d->dy && !gru) return MVAE_ERR_INVALID;
+  if (!d->dy && !d->dy_a && !gru) return MVAE_ERR_INVALID;
+  if (d->dy_a && (gru || !d->dy_w || d->dy_k < 128 || d->dy_k % 128 || d->dy_a_ld < d->dy_k || d->dy_w_ld < d->dy_k || d->dy_a_ld % epc || d->dy_w_ld % epc ||
+                  ((reinterpret_cast<uintptr_t>(d->dy_a) | reinterpret_cast<uintptr_t>(d->dy_w)) & 15)))
+    return MVAE_ERR_INVALID;
   if (d->lengths && !gru) return MVAE_ERR_UNSUPPORTED;
   for (int l = 0; l < NL; ++l) {
     if (!d->w_hhT[l] || (!gru && !d->cs[l]) || !d->gates[l] || !d->dG[l] || !d->dstate[l]) return MVAE_ERR_INVALID;
@@ -1243,6 +1246,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   // Tile / split choice (largest tile that still gives about one workgroup per CU): (256 x 128, 2 segments) for B >= 1024 at 4 x 1024,
   // (128 x 128, 2) at B = 512, (128 x 128, 4 = half segments) at B = 256, (128 x 64, 4) at B = 128.
   // MVAE_BWD_SPLIT: 0 = never, 1 = choose, 2 = (128 x 128, 2) whenever the shape allows, 2562 / 1284 / 644 = force (tests).
+  if (d->dy_a && (!pipe || dt != MVAE_BF16 || (long)B * d->dy_a_ld * sz >= (1L << 31) || (long)H * d->dy_w_ld * sz >= (1L << 31))) return MVAE_ERR_UNSUPPORTED;
   const int split_knob = tune_int("MVAE_BWD_SPLIT", 1);
   int nsplit = 0;
   if (split_knob && dt == MVAE_BF16 && pipe && vec && B % 128 == 0 && H % 128 == 0 && d->split_ws) {
@@ -1306,6 +1310,9 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       q.lda0 = ldg; q.K0 = 4 * H; q.W0 = d->w_hhT[l]; q.ldw0 = d->ldw_hhT[l];
       q.A1 = (l < NL - 1) ? adv(d->dG[l + 1], (long)t * B * ldg, dt) : nullptr;
       q.lda1 = ldg; q.K1 = 4 * H; q.W1 = (l < NL - 1) ? d->w_ihT[l + 1] : nullptr; q.ldw1 = (l < NL - 1) ? d->ldw_ihT[l + 1] : 0;
+      if (l == NL - 1 && d->dy_a) {       // the top cell has no layer above: its second K-segment contracts dy_t = dy_a[t] . dy_w^T instead
+        q.A1 = adv(d->dy_a, (long)t * B * d->dy_a_ld, dt); q.lda1 = d->dy_a_ld; q.K1 = d->dy_k; q.W1 = d->dy_w; q.ldw1 = d->dy_w_ld;
+      }
       q.dy = (l == NL - 1 && d->dy) ? d->dy + (long)t * B * d->dy_ld : nullptr; q.dy_ld = d->dy_ld;
       q.gates = adv(d->gates[l], (long)t * B * 4 * H, dt);
       q.c = gru ? nullptr : adv(d->cs[l], (long)t * B * H, dt);

@@ -359,7 +359,7 @@ size_t rnn_rowres_bwd_workspace(int layers, int T, int B, int H) { return (H == 
 // top layer first; layer l's input gradient (dx, scratch ping-pong) is layer l-1's dy
 int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   constexpr int H = 72;
-  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || !d->dy || d->lengths) return MVAE_ERR_UNSUPPORTED;
+  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || !d->dy || d->dy_a || d->lengths) return MVAE_ERR_UNSUPPORTED;
   const int NL = d->layers, T = d->T, B = d->B;
   for (int l = 0; l < NL; ++l)
     if (d->dh_last[l] || d->dh0[l] || d->h0[l]) return MVAE_ERR_UNSUPPORTED;

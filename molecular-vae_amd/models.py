@@ -149,6 +149,7 @@ class _Workspace:
 
 
 _LDPAD = 64   # elements added to power-of-two leading dimensions of the big recurrent operands
+_DYK = 128    # K extent (two 64-deep K-steps, so that the 4-way split backward can halve it) of the output-gradient product, see MolDecoder
 
 
 def _require_cuda(dev, what):
@@ -547,7 +548,8 @@ class MolDecoder(nn.Module):
             Cv = om.out_features
             Cp = _pad(Cv, 8)
             P["Wout"] = ws.get("Wout", (Cv, H), dt, dev)
-            P["WoutT"] = ws.get("WoutT", (H, Cp), dt, dev)
+            # bf16: W_out^T zero-padded to _DYK columns -- the backward contracts the logit gradients with it inside the top LSTM cell
+            P["WoutT"] = ws.get("WoutT", (H, _DYK if dt == torch.bfloat16 else Cp), dt, dev)
             ops.cast_transpose(om.weight, Cv, H, dst=P["Wout"], dstT=P["WoutT"])
         self._pack_key, self._packed = key, P
         return P
@@ -629,20 +631,25 @@ class _DecoderFn(torch.autograd.Function):
         cs = [W(f"cs{l}", (Lq, B, H), dt) for l in range(NL)]
         gates = [W(f"gates{l}", (Lq, B, G4), dt) for l in range(NL)]
         # K8 backward
-        dl = W("dl", (TB + 8, Cp), dt)[:TB]      # +8 rows: the TN tile reads 256-byte row segments past the last row
+        fuse_dy = dt == torch.bfloat16             # bf16: the top LSTM cell contracts dl . W_out itself (no [T, B, H] fp32 dy tensor)
+        ldl = _DYK if fuse_dy else Cp               # pad columns are allocated zero and never written
+        dl = W("dl", (TB + 8, ldl), dt)[:TB]        # +8 rows: the TN tile reads 256-byte row segments past the last row
         dlT = None
         if dt != torch.bfloat16:
             ldT = _pad(TB, 8) + 8
             dlT = W("dlT", (Cv, ldT), dt)
         with ops._Timed("hbm_softmax_bwd"):
             ops.softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, Cv)
-        dy = W("dy", (TB, H))
-        ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
+        dy = None
+        if not fuse_dy:
+            dy = W("dy", (TB, H))
+            ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
         # K7 backward
         dG = [W(f"dG{l}", (Lq, B, ldg), dt) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [P["ldwT"]] * NL, P["WihT"], [P["ldwT"]] * NL, dy, H, hs, ldh, cs, gates,
-                    dG, dstate, ldg=ldg, tag="dec_lstm_bwd")
+                    dG, dstate, ldg=ldg, tag="dec_lstm_bwd", dy_a=(dl if fuse_dy else None), dy_w=(P["WoutT"] if fuse_dy else None),
+                    dy_k=(_DYK if fuse_dy else 0))
 
         def weight_grads(part):
             """Everything that only produces parameter gradients (nothing on the path to dz): output head + LSTM weights.
@@ -650,9 +657,9 @@ class _DecoderFn(torch.autograd.Function):
             with ops._Timed("dec_lstm_wgrad" if part != 1 else "dec_lstm_wgrad_deferred"):
                 if part != 1:
                     if dt == torch.bfloat16:
-                        ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=Cp, ldb=ldh)
+                        ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldl, ldb=ldh)
                         dbp = W("dbout_p", (Cp,))
-                        ops.colsum_t(dl, TB, Cp, dbp, ldx=Cp)
+                        ops.colsum_t(dl, TB, Cp, dbp, ldx=ldl)
                         grads["decoded_mean.module.0.bias"].copy_(dbp[:Cv])
                     else:
                         hsT = W("wg_hsT_out", (H, ldT), dt)

@@ -371,7 +371,9 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
 
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dstate,
             ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dh0=None, tag=None,
-            drop_mask=None, drop_p=0.0, drop_seed=0):
+            drop_mask=None, drop_p=0.0, drop_seed=0, dy_a=None, dy_w=None, dy_k=0):
+    """dy_a [T*B, ld] / dy_w [H, ld] (dtype, zero-padded to dy_k columns): the output gradient as a product dy = dy_a . dy_w^T, contracted
+    by the top layer's cell itself (no [T, B, H] fp32 dy tensor)."""
     d = L.RnnBwdDesc()
     NL = len(w_hhT)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
@@ -382,6 +384,8 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     d.lengths = lengths.data_ptr() if lengths is not None else None
     d.dy = dy.data_ptr() if dy is not None else None
     d.dy_ld = dy_ld
+    if dy_a is not None:
+        d.dy_a, d.dy_a_ld, d.dy_w, d.dy_w_ld, d.dy_k = dy_a.data_ptr(), dy_a.stride(0), dy_w.data_ptr(), dy_w.stride(0), dy_k
     if dh_last is not None:
         _fill(d.dh_last, dh_last)
     _fill(d.hs, hs); d.ldh = ldh

@@ -28,7 +28,7 @@ def t(a, dt=torch.float32):
 
 def test_native_library_is_the_one_running():
     lib = L.load()
-    assert lib.mvae_abi_version() == L.ABI_VERSION == 3
+    assert lib.mvae_abi_version() == L.ABI_VERSION == 4
     assert os.path.samefile(L.LIB_PATH, os.path.join(ROOT, "molecular-vae_amd", "libmvae_hip.so"))
     assert any("libmvae_hip.so" in line for line in open("/proc/self/maps"))
 
@@ -106,6 +106,38 @@ def _lstm_case(dt, T, B, H, NL, In, seed=2):
     dx_h = dG[0][:, :, :G4].float().cpu().numpy().reshape(T * B, G4) @ p["g.weight_ih_l0"]
     errs["dx"] = rel(dx_h.reshape(T, B, In), dx)
     return errs
+
+
+@pytest.mark.parametrize("split", ["1", "0", "2", "1284", "644", "1281", "2562"])
+def test_lstm_bwd_output_gradient_as_a_product(split, monkeypatch):
+    """mvae_rnn_bwd with dy given as dy_a . dy_w^T (contracted by the top layer's cell as its second K-segment) against the same call with the
+    materialised fp32 dy = dy_a . dy_w^T, in every backward schedule (fused, 2- and 4-way split, unsplit 128 x 128, 256 x 128)."""
+    monkeypatch.setenv("MVAE_BWD_SPLIT", split)
+    torch.manual_seed(11)
+    dt, T, B, H, NL, C = torch.bfloat16, 4, 256, 128, 3, 35
+    G4, ldh, ldg, KP = 4 * H, H + 8, 4 * H + 8, 128
+    rnd = lambda *sh: torch.randn(*sh, device=dev)
+    hs = [(0.5 * rnd(T, B, ldh)).to(dt) for _ in range(NL)]
+    cs = [(0.5 * rnd(T, B, H)).to(dt) for _ in range(NL)]
+    gates = [torch.sigmoid(rnd(T, B, G4)).to(dt) for _ in range(NL)]
+    w_hhT = [(0.1 * rnd(H, G4)).to(dt) for _ in range(NL)]
+    w_ihT = [None] + [(0.1 * rnd(H, G4)).to(dt) for _ in range(1, NL)]
+    dy_a = torch.zeros(T * B + 8, KP, device=dev, dtype=dt); dy_a[:T * B, :C] = (0.3 * rnd(T * B, C)).to(dt)
+    dy_w = torch.zeros(H, KP, device=dev, dtype=dt); dy_w[:, :C] = (0.3 * rnd(H, C)).to(dt)
+    dy = dy_a[:T * B].float() @ dy_w.float().t()                      # what models.py used to materialise (fp32 accumulate of bf16 operands)
+    out = []
+    for mode in ("tensor", "product"):
+        dG = [torch.zeros(T, B, ldg, device=dev, dtype=dt) for _ in range(NL)]
+        dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
+        if mode == "tensor":
+            ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, w_hhT, [G4] * NL, w_ihT, [G4] * NL, dy, H, hs, ldh, cs, gates, dG, dstate, ldg=ldg)
+        else:
+            ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, w_hhT, [G4] * NL, w_ihT, [G4] * NL, None, 0, hs, ldh, cs, gates, dG, dstate, ldg=ldg,
+                        dy_a=dy_a[:T * B], dy_w=dy_w, dy_k=KP)
+        torch.cuda.synchronize()
+        out.append([g.float().cpu().numpy() for g in dG] + [d.cpu().numpy() for d in dstate])
+    for a, b in zip(*out):
+        assert np.abs(a).max() > 0 and rel(b, a) < 6e-3, rel(b, a)      # dG is stored in bf16: the two summation orders differ by an ulp of it
 
 
 @pytest.mark.parametrize("shape", [(128, 128, 64), (4096, 1024, 1024), (35, 1024, 4000), (300, 200, 513), (288, 72, 7), (130, 64, 61440 // 4)])
