@@ -186,7 +186,7 @@ int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
  * and, in the epilogue, the gate derivative dG^{l}_t (pre-activation gradient) and dc_{t-1}.
  *   w_hhT[l] [H, G*H], w_ihT[l] [in, G*H]: TRANSPOSED weights (K-contiguous for this contraction).
  *   dy       [T][B][H] fp32 gradient w.r.t. the stack output (row stride dy_ld).
- *   dy_a / dy_w / dy_k (optional, LSTM, dtype bf16): the same gradient given as a product  dy_t = dy_a[t] . dy_w^T  with
+ *   dy_a / dy_w / dy_k (optional, dtype bf16; GRU: rows of finished sequences must be zero in dy_a): the same gradient given as a product  dy_t = dy_a[t] . dy_w^T  with
  *            dy_a [T][B][dy_a_ld] dtype (e.g. the logit gradients of TimeDistributed(Linear), models.py:157) and dy_w [H][dy_w_ld] dtype
  *            (the Linear's weight, transposed), both zero-padded to dy_k columns, dy_k a multiple of 128: the TOP layer's cell contracts it
  *            as its second K-segment (that cell has no layer above), so the [T, B, H] fp32 tensor is never written or read.

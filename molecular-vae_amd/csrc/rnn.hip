@@ -551,6 +551,7 @@ struct StepTaskB {
   const void* h_prev; long ldhp;      // GRU: h_{t-1} [B, ldhp] dtype (nullptr = zeros)
   float* dh0;                         // GRU pseudo-cell t = -1: gradient w.r.t. the initial hidden state (fp32 [B,H]); gates == nullptr
   int t;
+  int seg1_full;                      // != 0: segment 1 is the output-gradient product dy_a . dy_w^T: contract all K1 columns (no GRU zero block)
   int drop;                           // != 0: the segment-1 contraction (gradient from the layer above) is multiplied by keep / (1 - p)
   const uint8_t* dmask;               // [B, H] injected keep mask of this cell's OUTPUT (nullptr: hash)
   uint32_t didx0;
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       const uint32_t lda = (uint32_t)q.lda1 * sz, ldw = (uint32_t)q.ldw1 * sz;
       auto offA = [&](int r) -> uint32_t { const int gm = m0 + r; return gm < B ? (uint32_t)gm * lda : PIPE_OOB; };
       auto offB = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < H ? (uint32_t)gn * ldw : PIPE_OOB; };
-      const int k1 = p.gru3 ? 3 * H : q.K1;              // GRU: the W_ih^T rows of gate slot 3 (k >= 3H) are a zero block
+      const int k1 = (p.gru3 && !q.seg1_full) ? 3 * H : q.K1;   // GRU: the W_ih^T rows of gate slot 3 (k >= 3H) are a zero block
       const int kh = (nsp == 4) ? k1 / 2 : k1, ko = half * kh * (int)sz;
       pipe_seg_init<T, BM, BN>(s1, q.A1 ? reinterpret_cast<const char*>(q.A1) + ko : nullptr, (uint32_t)B * lda - ko,
                                reinterpret_cast<const char*>(q.W1) + ko, (uint32_t)H * ldw - ko, offA, offB, kh, tid & 255);
@@ -1203,7 +1204,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   const int epc = (dt == MVAE_BF16) ? 8 : 4;
   const bool gru = d->cell == MVAE_CELL_GRU;
   if (!d->dy && !d->dy_a && !gru) return MVAE_ERR_INVALID;
-  if (d->dy_a && (gru || !d->dy_w || d->dy_k < 128 || d->dy_k % 128 || d->dy_a_ld < d->dy_k || d->dy_w_ld < d->dy_k || d->dy_a_ld % epc || d->dy_w_ld % epc ||
+  if (d->dy_a && (!d->dy_w || d->dy_k < 128 || d->dy_k % 128 || d->dy_a_ld < d->dy_k || d->dy_w_ld < d->dy_k || d->dy_a_ld % epc || d->dy_w_ld % epc ||
                   ((reinterpret_cast<uintptr_t>(d->dy_a) | reinterpret_cast<uintptr_t>(d->dy_w)) & 15)))
     return MVAE_ERR_INVALID;
   if (d->lengths && !gru) return MVAE_ERR_UNSUPPORTED;
@@ -1298,7 +1299,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
         q.A1 = nullptr; q.lda1 = ldg; q.K1 = 4 * H; q.W1 = nullptr; q.ldw1 = 0;
         q.dy = nullptr; q.dy_ld = 0; q.gates = nullptr; q.c = nullptr; q.c_prev = nullptr;
         q.dc_in = d->dstate[l]; q.dc_out = nullptr; q.dG = nullptr; q.ldg = ldg; q.h_prev = nullptr; q.ldhp = 0;
-        q.dh0 = d->dh0[l]; q.t = -1; q.drop = 0; q.dmask = nullptr; q.didx0 = 0;
+        q.dh0 = d->dh0[l]; q.t = -1; q.drop = 0; q.dmask = nullptr; q.didx0 = 0; q.seg1_full = 0;
       }
       if (n == 0) break;
     }
@@ -1310,8 +1311,10 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       q.lda0 = ldg; q.K0 = 4 * H; q.W0 = d->w_hhT[l]; q.ldw0 = d->ldw_hhT[l];
       q.A1 = (l < NL - 1) ? adv(d->dG[l + 1], (long)t * B * ldg, dt) : nullptr;
       q.lda1 = ldg; q.K1 = 4 * H; q.W1 = (l < NL - 1) ? d->w_ihT[l + 1] : nullptr; q.ldw1 = (l < NL - 1) ? d->ldw_ihT[l + 1] : 0;
+      q.seg1_full = 0;
       if (l == NL - 1 && d->dy_a) {       // the top cell has no layer above: its second K-segment contracts dy_t = dy_a[t] . dy_w^T instead
         q.A1 = adv(d->dy_a, (long)t * B * d->dy_a_ld, dt); q.lda1 = d->dy_a_ld; q.K1 = d->dy_k; q.W1 = d->dy_w; q.ldw1 = d->dy_w_ld;
+        q.seg1_full = 1;
       }
       q.dy = (l == NL - 1 && d->dy) ? d->dy + (long)t * B * d->dy_ld : nullptr; q.dy_ld = d->dy_ld;
       q.gates = adv(d->gates[l], (long)t * B * 4 * H, dt);

@@ -631,7 +631,8 @@ class _DecoderFn(torch.autograd.Function):
         cs = [W(f"cs{l}", (Lq, B, H), dt) for l in range(NL)]
         gates = [W(f"gates{l}", (Lq, B, G4), dt) for l in range(NL)]
         # K8 backward
-        fuse_dy = dt == torch.bfloat16             # bf16: the top LSTM cell contracts dl . W_out itself (no [T, B, H] fp32 dy tensor)
+        # bf16 (and a hidden size the LDS-direct loop serves): the top LSTM cell contracts dl . W_out itself (no [T, B, H] fp32 dy tensor)
+        fuse_dy = dt == torch.bfloat16 and (4 * H) % 64 == 0
         ldl = _DYK if fuse_dy else Cp               # pad columns are allocated zero and never written
         dl = W("dl", (TB + 8, ldl), dt)[:TB]        # +8 rows: the TN tile reads 256-byte row segments past the last row
         dlT = None

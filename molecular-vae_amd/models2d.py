@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .models import LinearWeights, Conv1dWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD
+from .models import LinearWeights, Conv1dWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _DYK
 from .mosesvae import _kmajor_gemm
 
 SEQ, VOCAB, HID, HP, NLAY = 120, 35, 501, 512, 3
@@ -129,7 +129,7 @@ class VAE(nn.Module):
             P["Wx0T"] = ws.get("Wx0T", (4, 4 * HP), f32, dev); ops.cast_transpose(P["Wx0"], 4 * HP, 4, dstT=P["Wx0T"])
             Cp = _pad(VOCAB, 8)
             w3p = torch.zeros(VOCAB, HP, device=dev); w3p[:, :HID].copy_(self.fc3.weight)
-            P["Wfc"] = ws.get("Wfc", (VOCAB, ldw), dt, dev); P["WfcT"] = ws.get("WfcT", (HP, Cp), dt, dev)
+            P["Wfc"] = ws.get("Wfc", (VOCAB, ldw), dt, dev); P["WfcT"] = ws.get("WfcT", (HP, _DYK if dt == torch.bfloat16 else Cp), dt, dev)
             ops.cast_transpose(w3p, VOCAB, HP, dst=P["Wfc"], dstT=P["WfcT"])
         self._pack_key, self._packed = key, P
         return P
@@ -228,21 +228,26 @@ class _Models2dFn(torch.autograd.Function):
 
         # ---- fc3 + softmax
         drecon = drecon.contiguous().float()
-        dl = W("dl", (TB + 8, Cp), dt)[:TB]
+        fuse_dy = dt == torch.bfloat16 and (4 * HP) % 64 == 0   # the top GRU cell contracts dl . W_fc3 itself
+        ldl = _DYK if fuse_dy else Cp
+        dl = W("dl", (TB + 8, ldl), dt)[:TB]
         ops.softmax_tb_bwd(recon, drecon, dl, None, B, SEQ, VOCAB)
         hsx = [W(f"hsx{l}", (SEQ + 1, B, ldh), dt) for l in range(NLAY)]
         out_seq = hsx[-1][1:].reshape(TB, ldh)
         dw3 = W("dw3", (VOCAB, HP))
-        _kmajor_gemm(ws, "fc3", dl, Cp, VOCAB, out_seq, ldh, HP, TB, dw3, dev)
+        _kmajor_gemm(ws, "fc3", dl, ldl, VOCAB, out_seq, ldh, HP, TB, dw3, dev)
         grads["fc3.weight"].copy_(dw3[:, :HID])
-        dbp = W("db3p", (Cp,)); ops.colsum_t(dl, TB, Cp, dbp, ldx=Cp); grads["fc3.bias"].copy_(dbp[:VOCAB])
-        dy = W("dy", (TB, HP)); ops.gemm_nt(dl, P["WfcT"], dy, TB, HP, Cp)
+        dbp = W("db3p", (Cp,)); ops.colsum_t(dl, TB, Cp, dbp, ldx=ldl); grads["fc3.bias"].copy_(dbp[:VOCAB])
+        dy = None
+        if not fuse_dy:
+            dy = W("dy", (TB, HP)); ops.gemm_nt(dl, P["WfcT"], dy, TB, HP, Cp)
         # ---- GRU stack, reverse wavefront
         gates = [W(f"gates{l}", (SEQ, B, 4 * HP), dt) for l in range(NLAY)]
         dG = [W(f"dG{l}", (SEQ, B, ldg), dt) for l in range(NLAY)]
         dstate = [W(f"dstate{l}", (2, B, HP)) for l in range(NLAY)]
         ops.rnn_bwd(L.CELL_GRU, dt, SEQ, B, HP, P["WhhT"], [P["ldwT"]] * NLAY, P["WihT"], [P["ldwT"]] * NLAY, dy, HP,
-                    [h[1:] for h in hsx], ldh, None, gates, dG, dstate, ldg=ldg, h0=[h[0] for h in hsx], ldh0=ldh, tag="m2d_gru_bwd")
+                    [h[1:] for h in hsx], ldh, None, gates, dG, dstate, ldg=ldg, h0=[h[0] for h in hsx], ldh0=ldh, tag="m2d_gru_bwd",
+                    dy_a=(dl if fuse_dy else None), dy_w=(P["WfcT"] if fuse_dy else None), dy_k=(_DYK if fuse_dy else 0))
         s4 = W("s4", (4 * HP,))
         tmp = W("dw_gru", (4 * HP, HP))
         for l in range(NLAY):

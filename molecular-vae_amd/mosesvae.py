@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD
+from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _DYK
 from .vocab import PaddedBatch, pad_batch
 
 
@@ -227,7 +227,7 @@ class VAE(nn.Module):
                 ops.cast_transpose(seq[2].weight, seq[2].out_features, seq[2].in_features, dstT=P[n + "_W2T"])
             P["WlatT"] = ws.get("WlatT", (dz, Hd), f32, dev); ops.cast_transpose(self.decoder_lat.weight, Hd, dz, dstT=P["WlatT"])
             Vp8 = _pad(V, 8)
-            P["Wfc"] = ws.get("Wfc", (V, Hd + _LDPAD), dt, dev); P["WfcT"] = ws.get("WfcT", (Hd, Vp8), dt, dev)
+            P["Wfc"] = ws.get("Wfc", (V, Hd + _LDPAD), dt, dev); P["WfcT"] = ws.get("WfcT", (Hd, _DYK if dt == torch.bfloat16 else Vp8), dt, dev)
             ops.cast_transpose(self.decoder_fc.weight, V, Hd, dst=P["Wfc"], dstT=P["WfcT"])
         self._pack_key, self._packed = key, P
         return P
@@ -347,15 +347,19 @@ class _MosesFn(torch.autograd.Function):
 
         # ---------------- decoder_fc + cross-entropy
         y_tb, loss2 = W("y_tb", (TB, V)), W("loss2", (2,))
-        dl = W("dl", (TB + 8, Vp8), dt)[:TB]
+        fuse_dy = dt == torch.bfloat16 and (4 * Hd) % 64 == 0   # the top GRU cell contracts dl . W_fc itself (pad / finished positions: zero rows in dl)
+        ldl = _DYK if fuse_dy else Vp8
+        dl = W("dl", (TB + 8, ldl), dt)[:TB]
         if drecon is None:
             drecon = torch.zeros((), device=dev)
         ops.ce_loss_bwd(y_tb, V, x_pad, mod.pad, loss2, g1(drecon), c(dy_ext), dl, B, T, V)
         hsx_d = [W(f"dec_hsx{l}", (T + 1, B, ldh_d), dt) for l in range(NL)]
         out_seq = hsx_d[-1][1:].reshape(TB, ldh_d)
-        _kmajor_gemm(ws, "fc", dl, Vp8, V, out_seq, ldh_d, Hd, TB, grads["decoder_fc.weight"], dev)
-        dbp = W("dbfc_p", (Vp8,)); ops.colsum_t(dl, TB, Vp8, dbp, ldx=Vp8); grads["decoder_fc.bias"].copy_(dbp[:V])
-        dyd = W("dy_dec", (TB, Hd)); ops.gemm_nt(dl, P["WfcT"], dyd, TB, Hd, Vp8)
+        _kmajor_gemm(ws, "fc", dl, ldl, V, out_seq, ldh_d, Hd, TB, grads["decoder_fc.weight"], dev)
+        dbp = W("dbfc_p", (Vp8,)); ops.colsum_t(dl, TB, Vp8, dbp, ldx=ldl); grads["decoder_fc.bias"].copy_(dbp[:V])
+        dyd = None
+        if not fuse_dy:
+            dyd = W("dy_dec", (TB, Hd)); ops.gemm_nt(dl, P["WfcT"], dyd, TB, Hd, Vp8)
         # ---------------- decoder GRU stack, reverse wavefront (+ gradient w.r.t. h_0 of every layer)
         ldg_d = 4 * Hd + _LDPAD
         gates_d = [W(f"dec_gates{l}", (T, B, 4 * Hd), dt) for l in range(NL)]
@@ -366,7 +370,8 @@ class _MosesFn(torch.autograd.Function):
                     [h[1:] for h in hsx_d], ldh_d, None, gates_d, dG_d, dstate_d, ldg=ldg_d, h0=[h[0] for h in hsx_d], ldh0=ldh_d,
                     lengths=lengths, dh0=dh0,
                     drop_mask=(None if drop is None or drop[2] is None else [drop[2][l] for l in range(NL - 1)]),
-                    drop_p=(drop[0] if drop else 0.0), drop_seed=(drop[1] if drop else 0), tag="moses_dec_bwd")
+                    drop_p=(drop[0] if drop else 0.0), drop_seed=(drop[1] if drop else 0), tag="moses_dec_bwd",
+                    dy_a=(dl if fuse_dy else None), dy_w=(P["WfcT"] if fuse_dy else None), dy_k=(_DYK if fuse_dy else 0))
         hd = [W(f"dec_hd{l}", (T, B, ldh_d), dt) for l in range(NL - 1)] if drop is not None else None
         s4 = W("dec_s4", (4 * Hd,))
         for l in range(NL):
