@@ -1,11 +1,17 @@
+#!/bin/bash
+# Per-kernel average durations of two library builds on ONE box: rocprofv3 --kernel-trace --stats over the kernel micro-benchmark
+# (bench.py refuses MVAE_* variables, so the library is switched under tests/bench_kernels.py):
+#   bash tests/tuning/prof_ab.sh libA.so libB.so [T] [B] [modes]
+A=$1; B_=$2; T=${3:-48}; BATCH=${4:-128}; MODES=${5:-bwd}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for lib in prev new; do
-  f=molecular-vae_amd/libmvae_hip.so; [ $lib = prev ] && f=molecular-vae_amd/libmvae_hip_prev.so
-  export MVAE_LIB=$GRAFT_REPO_ROOT/$f
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_ab_$lib -o p --output-format csv -- python3 tests/bench_kernels.py 48 128 bwd > /dev/null 2>&1
-  echo "== $lib"; python3 - <<PY
-import csv
-rows=list(csv.DictReader(open("gpurun_out/prof_ab_$lib/p_kernel_stats.csv")))
-for r in rows[:4]: print(r['Name'][:70], r['Calls'], round(float(r['AverageNs'])/1e3,2))
+for lib in $A $B_; do
+  export MVAE_LIB=$GRAFT_REPO_ROOT/$lib
+  d=gpurun_out/prof_ab_$(basename $lib .so)
+  rocprofv3 --kernel-trace --stats -d $d -o p --output-format csv -- python3 tests/bench_kernels.py $T $BATCH $MODES > /dev/null 2>&1
+  echo "== $(basename $lib)"
+  python3 - "$d/p_kernel_stats.csv" <<'PY'
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:4]:
+    print(f"  {r['Name'][:80]:80s} x{r['Calls']:>5s}  avg {float(r['AverageNs'])/1e3:8.2f} us")
 PY
 done
