@@ -1111,7 +1111,15 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
 #else
   a.dbg = 0;
 #endif
-  const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", (BJ == 64) ? 3 : (dt == MVAE_BF16 && BM == 64) ? 3 : 4) : 0;
+  // 64 x (32 x 4) bf16 tile: a 3-deep ring (72 KB) lets two workgroups share a CU, a 2-deep one (48 KB) three.  The shallower ring wins exactly
+  // when the third resident workgroup saves a round of workgroups: GRU 3 x 512 at B = 1024 is 768 tiles = 1.5 rounds of 512 but ONE round of
+  // 768 (MOSES 7.28 -> 7.08 ms / step, models2d 10.18 -> 9.75); with 512 tiles (LSTM 4 x 1024 at B = 256) the deeper ring stays ahead.
+  int nbuf_dflt = (BJ == 64) ? 3 : (dt == MVAE_BF16 && BM == 64) ? 3 : 4;
+  if (dt == MVAE_BF16 && BM == 64 && BJ == 32 && !BMW) {
+    const long nb = (long)((B + BM - 1) / BM) * ((H + BJ - 1) / BJ) * NL, cus = 256;
+    if ((nb + 3 * cus - 1) / (3 * cus) < (nb + 2 * cus - 1) / (2 * cus)) nbuf_dflt = 2;
+  }
+  const int nbuf = pipe ? tune_int("MVAE_NBUF_FWD", nbuf_dflt) : 0;
   size_t lds = (size_t)(nbuf > 0 ? nbuf : 2) * (BM + 4 * BJ) * KB;
   const size_t stage_bytes = (size_t)BM * 4 * (BJ + 4) * sizeof(float);     // epilogue staging tile
   if (lds < stage_bytes) lds = stage_bytes;
@@ -1174,7 +1182,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     }
     if (dt == MVAE_BF16) {
       FWD_CASE(bf16_t, 128, 0) FWD_CASE(bf16_t, 128, 3) FWD_CASE(bf16_t, 128, 4) FWD_CASE(bf16_t, 128, 5)
-      FWD_CASE(bf16_t, 64, 0) FWD_CASE(bf16_t, 64, 3) FWD_CASE(bf16_t, 64, 4) FWD_CASE(bf16_t, 64, 5)
+      FWD_CASE(bf16_t, 64, 0) FWD_CASE(bf16_t, 64, 2) FWD_CASE(bf16_t, 64, 3) FWD_CASE(bf16_t, 64, 4) FWD_CASE(bf16_t, 64, 5)
     } else {
       FWD_CASE(float, 128, 0) FWD_CASE(float, 128, 4) FWD_CASE(float, 64, 0) FWD_CASE(float, 64, 4) FWD_CASE(float, 32, 0) FWD_CASE(float, 32, 4)
     }

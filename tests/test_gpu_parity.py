@@ -257,7 +257,8 @@ def test_row_resident_lstm_with_and_without_hoisted_input_projection(hoist, monk
 
 
 @pytest.mark.parametrize("env", [{"MVAE_BJ": "64"}, {"MVAE_BM": "128", "MVAE_NBUF_FWD": "4", "MVAE_NBUF_BWD": "5"},
-                                 {"MVAE_BM": "64", "MVAE_BJ": "32", "MVAE_NBUF_FWD": "5", "MVAE_NBUF_BWD": "3"}])
+                                 {"MVAE_BM": "64", "MVAE_BJ": "32", "MVAE_NBUF_FWD": "5", "MVAE_NBUF_BWD": "3"},
+                                 {"MVAE_BM": "64", "MVAE_BJ": "32", "MVAE_NBUF_FWD": "2", "MVAE_FWD_GM": "0"}])
 def test_lstm_tile_variants_vs_oracle(env, monkeypatch):
     """The tile / ring-depth variants the heuristics pick at production sizes, forced here at an oracle-checkable size."""
     for k, v in env.items():
