@@ -1271,6 +1271,14 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     // small stacks (GRU 3 x 512 at B = 128: 96 workgroups of (128 x 64, 4)) still beat the fused 64 x 64 tiles: 15 vs 25 us / launch
     if (!nsplit && split_knob == 1 && (4 * H) % (2 * ke) == 0 && (long)(B / 128) * (H / 64) * 4 * NL >= 64) { BM = 128; BN = 64; nsplit = 4; }
     if (nsplit > 1 && d->split_ws_bytes < (size_t)NL * nsplit * B * H * sizeof(float)) nsplit = 0;
+    // Short contractions (GRU 3 x 512: 6H = 3072 columns): a fused 64 x 64 tile streams under 1 MB, and with the pipelined straight-line
+    // epilogue one fused launch beats the split GEMM + element-wise pair once it has about a workgroup per CU: MOSES B = 1024 6.99 -> 6.64,
+    // B = 512 5.58 -> 5.10 ms / step (B <= 256: 4.43 vs 4.48, the split pair stays); 4 x 1024 (8H = 8192 columns, 2 MB per tile) never.
+    if (split_knob == 1 && nsplit > 1) {
+      const long fused_tiles = (long)((B + 63) / 64) * ((H + 63) / 64) * NL;
+      const long kcols = (gru && tune_int("MVAE_GRU3", 1) ? 6L : 8L) * H;
+      if (fused_tiles >= 192 && 128 * kcols * sz <= (1L << 20)) { nsplit = 0; BM = 64; BN = 64; }
+    }
   }
   const bool big_fused = nsplit == 1;            // (128 x 128, unsplit): the wave-specialised kernel with the gate-derivative epilogue fused
   if (big_fused) nsplit = 0;
