@@ -238,6 +238,7 @@ def test_gemm_tn_bf16_tile_variants(shape, bm, monkeypatch):
     (torch.float32, 4, 200, 64, 2, 8, 2e-5),      # pipelined path, f32 MFMA
     (torch.bfloat16, 3, 256, 192, 4, 8, 3e-2),    # 4 layers, 128-row tiles
     (torch.bfloat16, 1, 9, 64, 2, 8, 3e-2),       # T = 1 edge case
+    (torch.bfloat16, 3, 512, 512, 3, 8, 3e-2),    # short contraction with a workgroup per CU: the fused backward is chosen over the split pair
 ])
 def test_lstm_wavefront_fwd_bwd_vs_oracle(case):
     dt, T, B, H, NL, In, tol = case
