@@ -38,6 +38,8 @@ extern "C" {
 
 #define MVAE_F32 0
 #define MVAE_BF16 1
+#define MVAE_F32X3 2   /* mvae_gemm_nt only: fp32 operands in memory, products on the bf16 MFMA as hi.hi + hi.lo + lo.hi (x = hi + lo in bf16):
+                        ~16 mantissa bits per product, fp32 accumulation; shapes the LDS-direct loop does not serve run in exact fp32 */
 
 #define MVAE_ACT_NONE 0
 #define MVAE_ACT_SELU 1           /* models.py:58-68 */
@@ -260,6 +262,9 @@ size_t mvae_conv1d_selu_bwd_workspace(int B, int W, int Cin, int ldx, int Cout, 
  * models2d.VAE encoder (models2d.py:12-14,24-27). */
 int mvae_conv1d_act_fwd(int act, int B, int W, int ldx, int64_t x_bs, int Cout, int k, const float* x, const float* wp, const float* bias,
                         float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+/* OR-ed into `act` of mvae_conv1d_act_bwd: the input-gradient AND weight-gradient GEMMs multiply in the MVAE_F32X3 form (gradients only: the bf16 training mode,
+ * whose decoder gradients are bf16-accurate anyway; the forward conv and the exact-fp32 mode never use it). */
+#define MVAE_CONV_BWD_X3 0x100
 int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
                         const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                         void* ws, size_t ws_bytes, void* stream);

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 
 ABI_VERSION = 4
-MVAE_F32, MVAE_BF16 = 0, 1
+MVAE_F32, MVAE_BF16, MVAE_F32X3 = 0, 1, 2
+CONV_BWD_X3 = 0x100
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
 CELL_LSTM, CELL_GRU = 0, 1
 MAX_LAYERS = 8

@@ -113,6 +113,8 @@ int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, i
                         const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                         void* ws, size_t ws_bytes, void* stream) {
   if (!dy || !y || !x || !dzp || !dw || !db || !ws) return MVAE_ERR_INVALID;
+  const bool x3 = (act & MVAE_CONV_BWD_X3) != 0;
+  act &= ~MVAE_CONV_BWD_X3;
   if (act != MVAE_ACT_NONE && act != MVAE_ACT_SELU && act != MVAE_ACT_RELU) return MVAE_ERR_INVALID;
   if (B < 1 || Cin < 1 || Cout < 1 || k < 1 || W < k || ldx < Cin || ldo < Cout || (ldx & 3) || (ldo & 3) || (x_bs & 3) ||
       x_bs < (int64_t)W * ldx) return MVAE_ERR_INVALID;
@@ -131,12 +133,12 @@ int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, i
   if ((rc = launch_colsum(B * Wp, Cout, dzp, ldo, db, gws, gws_bytes, st))) return rc;         // pad rows are zero
   // dwp[o][kc] = sum over output positions of dz[(b,w)][o] * window(b,w)[kc]
   const float* dz0 = dzp + (long)(k - 1) * ldo;
-  if ((rc = launch_gemm_tn_f32(Cout, k * ldx, B * Wout, dz0, ldo, Wout, (long)Wp * ldo, x, ldx, Wout, x_bs, dwp, (long)k * ldx, 0, gws, gws_bytes, st))) return rc;
+  if ((rc = launch_gemm_tn_f32(Cout, k * ldx, B * Wout, dz0, ldo, Wout, (long)Wp * ldo, x, ldx, Wout, x_bs, dwp, (long)k * ldx, 0, gws, gws_bytes, st, x3))) return rc;
   hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3(cgrid((long)Cout * Cin * k)), dim3(256), 0, st, Cin, Cout, k, dwp, ldx, dw);
   MVAE_CHECK_HIP(hipGetLastError());
   if (dx) {
     // dx[(b,w)][c] = sum_{j,o} dzp[b][w + j][o] * w[o][c][k-1-j]: full correlation = the forward GEMM on the padded dz
-    if ((rc = launch_gemm_nt_grouped(MVAE_F32, B * W, Cin, k * ldo, dzp, ldo, W, (long)Wp * ldo, (long)B * Wp * ldo, wq, (long)k * ldo, dx, lddx,
+    if ((rc = launch_gemm_nt_grouped(x3 ? MVAE_F32X3 : MVAE_F32, B * W, Cin, k * ldo, dzp, ldo, W, (long)Wp * ldo, (long)B * Wp * ldo, wq, (long)k * ldo, dx, lddx,
                                      MVAE_F32, nullptr, MVAE_ACT_NONE, 0, gws, gws_bytes, st))) return rc;
   }
   return MVAE_OK;

@@ -41,7 +41,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <typename T, int BM, int BN, bool PIPE>
+// X3 (fp32 operands, LDS-direct loop only): products on the bf16 MFMA as hi.hi + hi.lo + lo.hi, see tile_pipe.hpp split_x3
+template <typename T, int BM, int BN, bool PIPE, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const uint32_t bytesA = (uint32_t)(p.a_total * sz - kbeg * sz), bytesB = (uint32_t)((long)p.N * p.ldb * sz - kbeg * sz);
     pipe_seg_init<T, BM, BN>(s0, A + kbeg, bytesA, B + kbeg, bytesB, offA, offB, (int)(kend - kbeg), tid);
     s1 = s0; s1.nk = 0;
-    tile_gemm_pipe<T, BM, BN, MI, NI, NBUF, NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+    tile_gemm_pipe<T, BM, BN, MI, NI, NBUF, NI, 0, X3>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
   } else {
     tile_gemm_segment<T, BM, BN, MI, NI>(smem, rowA, rowB, kbeg, kend, wm * WM, brow, acc, tid);
   }
@@ -330,6 +331,7 @@ Plan make_plan(int M, int N, int K, int dtype) {
 }  // namespace
 
 size_t gemm_nt_workspace_bytes(int M, int N, int K, int dtype) {
+  if (dtype == MVAE_F32X3) dtype = MVAE_F32;
   Plan pl = make_plan(M, N, K, dtype);
   return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
 }
@@ -344,6 +346,8 @@ int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long l
                            void* ws, size_t ws_bytes, hipStream_t st) {
   if (M <= 0 || N <= 0) return MVAE_OK;
   if (K < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
+  const bool x3 = dtype == MVAE_F32X3;           // fp32 operands, 3 x bf16 products (only the LDS-direct loop has the form; otherwise exact fp32)
+  if (x3) dtype = MVAE_F32;
   if (dtype != MVAE_F32 && dtype != MVAE_BF16) return MVAE_ERR_INVALID;
   if (c_dtype != MVAE_F32 && c_dtype != MVAE_BF16) return MVAE_ERR_INVALID;
   if (accumulate && c_dtype != MVAE_F32) return MVAE_ERR_INVALID;
@@ -376,17 +380,27 @@ int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long l
     hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                \
   } while (0)
 #define MVAE_GEMM_LAUNCH(TT_, BM_, PIPE_) MVAE_GEMM_LAUNCH2(TT_, BM_, BM_, PIPE_)
+#define MVAE_GEMM_LAUNCH3(BM_)                                                                        \
+  do {                                                                                                \
+    auto kern = gemm_nt_kernel<float, BM_, BM_, true, true>;                                          \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                \
+  } while (0)
   if (pl.bn == 32) {
     if (pipe) MVAE_GEMM_LAUNCH2(float, 128, 32, true); else MVAE_GEMM_LAUNCH2(float, 128, 32, false);
   } else if (dtype == MVAE_BF16) {
     if (pl.bm == 128) { if (pipe) MVAE_GEMM_LAUNCH(bf16_t, 128, true); else MVAE_GEMM_LAUNCH(bf16_t, 128, false); }
     else { if (pipe) MVAE_GEMM_LAUNCH(bf16_t, 64, true); else MVAE_GEMM_LAUNCH(bf16_t, 64, false); }
+  } else if (x3 && pipe) {
+    if (pl.bm == 128) MVAE_GEMM_LAUNCH3(128); else MVAE_GEMM_LAUNCH3(64);
   } else {
     if (pl.bm == 128) { if (pipe) MVAE_GEMM_LAUNCH(float, 128, true); else MVAE_GEMM_LAUNCH(float, 128, false); }
     else { if (pipe) MVAE_GEMM_LAUNCH(float, 64, true); else MVAE_GEMM_LAUNCH(float, 64, false); }
   }
 #undef MVAE_GEMM_LAUNCH
 #undef MVAE_GEMM_LAUNCH2
+#undef MVAE_GEMM_LAUNCH3
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;
@@ -546,6 +560,10 @@ int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, con
 // =====================================================================================================================
 constexpr int TNF_BM = 64, TNF_KS = 32, TNF_LD = 80;
 
+// X3: the products go to the bf16 MFMA as hi.hi + hi.lo + lo.hi (split_x3 in tile_pipe.hpp).  The 16x16x32 fragment of lane l is eight k-values
+// of column (l & 15) for k-slice (l >> 4); WHICH eight is free as long as A and B agree, so slice f takes rows f, f + 4, ..., f + 28 of the
+// stage -- exactly the eight values the fp32 form already reads for its eight 16x16x4 MFMAs.  12 bf16 MFMAs per stage instead of 32 fp32 ones.
+template <bool X3>
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
   __shared__ float As[2][TNF_KS * TNF_LD];
   __shared__ float Bs[2][TNF_KS * TNF_LD];
@@ -633,12 +651,34 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
         bf[k4][0] = bs[k4 * 4 * TNF_LD]; bf[k4][1] = bs[k4 * 4 * TNF_LD + 16];
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (X3) {
+        static_assert(TNF_KS == 32, "one 16x16x32 MFMA step per stage");
+        uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 a0 = {__builtin_bit_cast(uint32_t, af[0][i]), __builtin_bit_cast(uint32_t, af[1][i]), __builtin_bit_cast(uint32_t, af[2][i]), __builtin_bit_cast(uint32_t, af[3][i])};
+          const u32x4 a1 = {__builtin_bit_cast(uint32_t, af[4][i]), __builtin_bit_cast(uint32_t, af[5][i]), __builtin_bit_cast(uint32_t, af[6][i]), __builtin_bit_cast(uint32_t, af[7][i])};
+          const u32x4 b0 = {__builtin_bit_cast(uint32_t, bf[0][i]), __builtin_bit_cast(uint32_t, bf[1][i]), __builtin_bit_cast(uint32_t, bf[2][i]), __builtin_bit_cast(uint32_t, bf[3][i])};
+          const u32x4 b1 = {__builtin_bit_cast(uint32_t, bf[4][i]), __builtin_bit_cast(uint32_t, bf[5][i]), __builtin_bit_cast(uint32_t, bf[6][i]), __builtin_bit_cast(uint32_t, bf[7][i])};
+          split_x3(a0, a1, ah[i], al[i]);
+          split_x3(b0, b1, bh[i], bl[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            mma16<bf16_t>(al[i], bh[j], acc[i][j]);
+            mma16<bf16_t>(ah[i], bl[j], acc[i][j]);
+            mma16<bf16_t>(ah[i], bh[j], acc[i][j]);
+          }
+      } else {
 #pragma unroll
       for (int k4 = 0; k4 < TNF_KS / 4; ++k4) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][0], bf[k4][0], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][0], bf[k4][1], acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][1], bf[k4][0], acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][1], bf[k4][1], acc[1][1], 0, 0, 0);
+      }
       }
       if (s + 1 < nst) store_stage(cur ^ 1);
       __syncthreads();
@@ -693,7 +733,7 @@ size_t gemm_tn_f32_workspace_bytes(int M, int N, int R) {
 // A: rows of M floats, B: rows of N floats; group == 0 -> plain row-major [R][ld].  Row starts must be 16-byte aligned
 // (ld, gstride multiples of 4, bases 16-byte aligned) -- checked here.
 int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_group, long a_gstride, const float* B, long ldb, int b_group,
-                       long b_gstride, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                       long b_gstride, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool x3) {
   if (M <= 0 || N <= 0) return MVAE_OK;
   if (R < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
   if ((lda | ldb | a_gstride | b_gstride) & 3) return MVAE_ERR_INVALID;
@@ -711,7 +751,8 @@ int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_grou
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
     p.partial = reinterpret_cast<float*>(ws);
   }
-  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);
+  if (x3) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;

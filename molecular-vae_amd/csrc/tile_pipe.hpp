@@ -91,6 +91,46 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// fp32 operands multiplied on the bf16 MFMA as  hi.hi + hi.lo + lo.hi  (x = hi + lo, hi = x truncated to bf16, lo = bf16(x - hi)):
+// about 16 mantissa bits per product at 3/16 of the f32 MFMA's cycles.  Eight floats per lane (the two 16-byte chunks of a K-step) become
+// one bf16x8 fragment each for hi and lo; A and B use the same element order, which is all a dot product needs.
+__device__ __forceinline__ void split_x3(const u32x4& c0, const u32x4& c1, uint4& hi, uint4& lo) {
+  const uint32_t x[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t h0 = x[2 * j] & 0xffff0000u, h1 = x[2 * j + 1] & 0xffff0000u;
+    const float l0 = __builtin_bit_cast(float, x[2 * j]) - __builtin_bit_cast(float, h0);
+    const float l1 = __builtin_bit_cast(float, x[2 * j + 1]) - __builtin_bit_cast(float, h1);
+    h[j] = (h0 >> 16) | h1;
+    l[j] = (uint32_t)f2bf(l0) | ((uint32_t)f2bf(l1) << 16);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]); lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+template <int MI, int NI, int JS, int BOUT>
+__device__ __forceinline__ void tile_mma_asm_x3(uint32_t a_base, uint32_t b_base, const uint32_t (&a_lane)[2], const uint32_t (&b_lane)[2],
+                                                f32x4 (&acc)[MI][NI]) {
+  u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
+  FragRead<0, MI, 16 * KB>::run(a0, a_base + a_lane[0]);
+  FragReadB<0, NI, JS, BOUT>::run(b0, b_base + b_lane[0]);
+  FragRead<0, MI, 16 * KB>::run(a1, a_base + a_lane[1]);
+  FragReadB<0, NI, JS, BOUT>::run(b1, b_base + b_lane[1]);
+  wait_lgkmcnt<0>();
+  uint4 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) split_x3(a0[mi], a1[mi], ah[mi], al[mi]);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) split_x3(b0[ni], b1[ni], bh[ni], bl[ni]);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      mma16<bf16_t>(al[mi], bh[ni], acc[mi][ni]);       // small terms first
+      mma16<bf16_t>(ah[mi], bl[ni], acc[mi][ni]);
+      mma16<bf16_t>(ah[mi], bh[ni], acc[mi][ni]);
+    }
+}
+
 // MFMAs of one K-step from LDS byte addresses (stage base already added).  JS / BOUT: layout of the wave's n-sub-tiles
 // (FragReadB).  a_lane / b_lane: per-lane byte offsets of (row l&15, chunk kk*4 + l>>4)
 // for kk = 0,1 relative to the wave's first A / B row.
@@ -146,9 +186,10 @@ __device__ __forceinline__ void pipe_issue_stage(char* smem, const PipeSeg<BM, B
 }
 
 // acc += sum over segment 0 then segment 1 of A_tile . B_tile^T.   smem: NBUF * (BM + BN) * 128 bytes.
-template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT>
+template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT, bool X3 = false>
 __device__ __forceinline__ void tile_gemm_pipe(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int arow0,
                                                int brow0, f32x4 (&acc)[MI][NI], int tid) {
+  static_assert(!X3 || std::is_same<T, float>::value, "the 3 x bf16 product form takes fp32 operands");
   constexpr int STAGE = (BM + BN) * KB;
   constexpr int LPS = (BM + BN) * 8 / 256;          // buffer loads per thread per stage
   static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
@@ -175,7 +216,8 @@ __device__ __forceinline__ void tile_gemm_pipe(char* smem, const PipeSeg<BM, BN>
     asm volatile("" ::: "memory");                            // keep the fragment reads below the barrier
     if (kt + NBUF - 1 < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, wave);   // refill the buffer stage kt-1 used
     const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
-    tile_mma_asm<T, MI, NI, JS, BOUT>(st, st, a_lane, b_lane, acc);
+    if constexpr (X3) tile_mma_asm_x3<MI, NI, JS, BOUT>(st, st, a_lane, b_lane, acc);
+    else tile_mma_asm<T, MI, NI, JS, BOUT>(st, st, a_lane, b_lane, acc);
   }
   __builtin_amdgcn_s_barrier();                               // LDS free for the caller (epilogue scratch / next use)
 }

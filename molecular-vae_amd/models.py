@@ -264,6 +264,7 @@ class MolEncoder(nn.Module):
         self.dense_1 = nn.Sequential(LinearWeights((h_size - (18 * 3) + 3) * 64, 512), SELU(inplace=True))
         self.lmbd = Lambda(512, o)
         self._ws = _Workspace()
+        self.fast_grad_gemms = False      # set by MolecularVAE in bf16 mode (conv input-gradient GEMMs as 3 x bf16 products)
         self._pack_key = None
         self._packed = {}
 
@@ -457,12 +458,14 @@ class _EncoderFn(torch.autograd.Function):
         x1, y1, y2, y3 = W("x1", (B * Hp, L1)), W("y1", (B * W1, O1)), W("y2", (B * W2, O2)), W("y3", (B * W3, C3))
         dy2, dy1, dx1 = W("dy2", (B * W2, O2)), W("dy1", (B * W1, O1)), W("dx1", (B * H, L1))
         dzp3, dzp2, dzp1 = W("dzp3", (B * (W3 + 2 * k - 2), C3)), W("dzp2", (B * (W2 + 2 * k - 2), O2)), W("dzp1", (B * (W1 + 2 * k - 2), O1))
+        # bf16 training mode: input-gradient GEMMs as 3 x bf16 products (forward conv stays exact fp32); MVAE_CONV_X3=0: A/B knob
+        x3 = bool(mod.fast_grad_gemms) and os.environ.get("MVAE_CONV_X3", "1") != "0"
         ops.conv1d_selu_bwd(B, W2, c3.in_channels, O2, W2 * O2, C3, C3, k, dy3, y3, y2, P["c3_wq"], dzp3,
-                            grads["conv_3.0.weight"], grads["conv_3.0.bias"], dy2, O2)
+                            grads["conv_3.0.weight"], grads["conv_3.0.bias"], dy2, O2, x3=x3)
         ops.conv1d_selu_bwd(B, W1, c2.in_channels, O1, W1 * O1, c2.out_channels, O2, k, dy2, y2, y1, P["c2_wq"], dzp2,
-                            grads["conv_2.0.weight"], grads["conv_2.0.bias"], dy1, O1)
+                            grads["conv_2.0.weight"], grads["conv_2.0.bias"], dy1, O1, x3=x3)
         ops.conv1d_selu_bwd(B, H, Lq, L1, Hp * L1, c1.out_channels, O1, k, dy1, y1, x1, P["c1_wq"], dzp1,
-                            grads["conv_1.0.weight"], grads["conv_1.0.bias"], dx1, L1)
+                            grads["conv_1.0.weight"], grads["conv_1.0.bias"], dx1, L1, x3=x3)
         dhs = W("dhs", (Lq, B, H))
         ops.cast_transpose(dx1, B * H, Lq, dstT=dhs.view(Lq, B * H), lds=L1)          # dhs[t][b][w] = dx1[(b, w)][t]
         # K2 backward (reverse wavefront) + weight gradients
@@ -729,6 +732,9 @@ class MolecularVAE(nn.Module):
         self.decoder = MolDecoder(i=o, o=i, c=c, dtype=dtype)
         self.decoder.__dict__["_peer"] = weakref.ref(self.encoder)
         self.prepack_decoder = True       # refresh the decoder's weight shadows on the side stream beside the encoder's forward
+        # bf16 mode: the encoder's conv INPUT-gradient GEMMs multiply as 3 x bf16 products (~16 mantissa bits, 3/16 of the f32 MFMA cycles);
+        # the forward pass of the encoder (what mu / logvar / the ELBO are made of) is exact fp32 in both modes
+        self.encoder.fast_grad_gemms = dtype == torch.bfloat16
 
     def forward(self, x, eps=None):
         ev = None

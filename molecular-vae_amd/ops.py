@@ -92,11 +92,15 @@ class Scratch:
         return b
 
 
-def gemm_nt(A, B, out, M, N, K, lda=None, ldb=None, ldc=None, bias=None, act=L.ACT_NONE, accumulate=False):
-    """out[M,N] = act(A[M,K] . B[N,K]^T + bias).  A, B same dtype (f32 / bf16); out f32 or bf16."""
+def gemm_nt(A, B, out, M, N, K, lda=None, ldb=None, ldc=None, bias=None, act=L.ACT_NONE, accumulate=False, x3=False):
+    """out[M,N] = act(A[M,K] . B[N,K]^T + bias).  A, B same dtype (f32 / bf16); out f32 or bf16.
+    x3 (fp32 operands): products on the bf16 MFMA as hi.hi + hi.lo + lo.hi (MVAE_F32X3, ~16 mantissa bits)."""
     lib = L.load()
     dt = dt_code(A.dtype)
     assert B.dtype == A.dtype
+    if x3:
+        assert A.dtype == torch.float32
+        dt = L.MVAE_F32X3
     lda = A.stride(0) if lda is None else lda
     ldb = B.stride(0) if ldb is None else ldb
     ldc = out.stride(0) if ldc is None else ldc
@@ -270,8 +274,11 @@ def conv1d_selu_fwd(x, B, W, ldx, x_bs, Cout, k, wp, bias, y, ldy, act=L.ACT_SEL
           "mvae_conv1d_act_fwd")
 
 
-def conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, db, dx, lddx, act=L.ACT_SELU):
+def conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, db, dx, lddx, act=L.ACT_SELU, x3=False):
+    """x3: the input-gradient GEMM multiplies its fp32 operands as 3 x bf16 products (MVAE_CONV_BWD_X3: gradients of the bf16 training mode)."""
     lib = L.load()
+    if x3:
+        act = act | L.CONV_BWD_X3
     need = lib.mvae_conv1d_selu_bwd_workspace(B, W, Cin, ldx, Cout, ldo, k)
     ws = Scratch.get(need, dy.device)
     check(lib.mvae_conv1d_act_bwd(act, B, W, Cin, ldx, x_bs, Cout, ldo, k, ptr(dy), ptr(y), ptr(x), ptr(wq), ptr(dzp), ptr(dw), ptr(db),

@@ -49,6 +49,20 @@ def test_gemm_nt(dt, tol, shape):
     assert rel(out.cpu().numpy(), ref) < tol
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 256), (4096, 120, 2304), (300, 64, 1152)])
+def test_gemm_nt_f32_operands_as_three_bf16_products(shape):
+    """MVAE_F32X3: fp32 operands multiplied as hi.hi + hi.lo + lo.hi on the bf16 MFMA (the conv input-gradient GEMMs of the bf16 training
+    mode): about 16 mantissa bits per product -- three orders of magnitude tighter than plain bf16, looser than the exact-fp32 kernel."""
+    M, N, K = shape
+    rs = np.random.RandomState(M + N)
+    A, B = t(rs.standard_normal((M, K))), t(rs.standard_normal((N, K)))
+    ref = A.double().cpu().numpy() @ B.double().cpu().numpy().T
+    out3 = torch.full((M, N), float("nan"), device=dev); ops.gemm_nt(A, B, out3, M, N, K, x3=True)
+    out1 = torch.full((M, N), float("nan"), device=dev); ops.gemm_nt(A, B, out1, M, N, K)
+    e3, e1 = rel(out3.cpu().numpy(), ref), rel(out1.cpu().numpy(), ref)
+    assert e1 < 5e-6 and e1 < e3 < 3e-5, (e1, e3)
+
+
 def _lstm_case(dt, T, B, H, NL, In, seed=2):
     rs = np.random.RandomState(seed)
     G4 = 4 * H
@@ -321,6 +335,11 @@ def test_conv1d_selu_sliding_window_vs_oracle(case):
     ops.conv1d_selu_bwd(B, W, Cin, ldx, Wbuf * ldx, Cout, ldo, k, dyd, y, xd, wq, dzp, dw, db, dx, ldx)
     assert rel(dw.cpu().numpy(), dw_ref) < 1e-5 and rel(db.cpu().numpy(), db_ref) < 1e-5      # f32 sums of up to 3e4 terms vs f64
     assert rel(dx.view(B, W, ldx)[:, :, :Cin].cpu().numpy().transpose(0, 2, 1), dx_ref) < 1e-5
+    # the bf16 training mode's form of the two gradient GEMMs (fp32 operands as 3 x bf16 products, MVAE_CONV_BWD_X3): ~16 mantissa bits
+    dw3 = torch.empty_like(dw); db3 = torch.empty_like(db); dx3 = torch.zeros_like(dx)
+    ops.conv1d_selu_bwd(B, W, Cin, ldx, Wbuf * ldx, Cout, ldo, k, dyd, y, xd, wq, dzp, dw3, db3, dx3, ldx, x3=True)
+    assert rel(dw3.cpu().numpy(), dw_ref) < 5e-5 and rel(db3.cpu().numpy(), db_ref) < 1e-5
+    assert rel(dx3.view(B, W, ldx)[:, :, :Cin].cpu().numpy().transpose(0, 2, 1), dx_ref) < 5e-5
 
 
 def test_small_ops_vs_oracle():
