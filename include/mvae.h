@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 4
+#define MVAE_ABI_VERSION 5
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -324,6 +324,10 @@ int mvae_expand_indices(const uint8_t* store, const int64_t* rows, int B, int L,
  *     (row t*B+b, leading dimension ldl); loss2[0] = loss, loss2[1] = number of counted tokens.  Backward writes dlogits in
  *     `dtype` with zero-padded columns V..ldd-1 (the next GEMM's K), adding an optional external dy given in [B,T,V] layout.
  *   mvae_permute102: [T,B,V] -> [B,T,V] (the `y` return value); mvae_relu_bwd: dy *= (y > 0) in place.
+ *   mvae_mask_rows_tb: rows (t*B + b) with t >= lengths[b] of a time-major [T*B, ld] buffer := 0 (ld * sizeof(dtype) a multiple of 16).
+ *     pad_packed_sequence (mosesvae.py:189) emits zeros at finished positions, so no gradient reaches h there: when an external gradient
+ *     w.r.t. the returned logits was added to dl, those rows are cleared before mvae_rnn_bwd contracts dl as dy_a (the decoder_fc weight /
+ *     bias gradients are taken from the unmasked dl first).
  */
 int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* stream);
 int mvae_moses_latent_bwd(int B, int dz, const float* mu, const float* logvar, const float* eps, const float* dz_in, const float* dkl,
@@ -335,6 +339,7 @@ int mvae_ce_loss_bwd(int dtype, int B, int T, int V, const float* logits, int64_
                      const float* grad_out, const float* dy_ext, void* dl, int64_t ldd, void* stream);
 int mvae_permute102(int T, int B, int V, const float* in, float* out, void* stream);
 int mvae_relu_bwd(int64_t n, float* dy, const float* y, void* stream);
+int mvae_mask_rows_tb(int dtype, int T, int B, int64_t ld, const int32_t* lengths, void* buf, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Optimiser surface (K14 + K15): torch.nn.utils.clip_grad_norm_(params, max_norm) (train.py:102) followed by

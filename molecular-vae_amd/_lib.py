@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # run with any MVAE_* variable set, so a measured number always comes from the product library.
 LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MVAE_F32, MVAE_BF16, MVAE_F32X3 = 0, 1, 2
 CONV_BWD_X3 = 0x100
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
@@ -119,6 +119,7 @@ SIGNATURES = {
     "mvae_ce_loss_bwd": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mvae_permute102": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "mvae_relu_bwd": (_i, [_i64, _vp, _vp, _vp]),
+    "mvae_mask_rows_tb": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp]),
     "mvae_sumsq_workspace": (_sz, [_i64]),
     "mvae_sumsq": (_i, [_i64, _vp, _vp, _vp]),
     "mvae_clip_adam": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),

@@ -620,6 +620,16 @@ __global__ __launch_bounds__(256) void ce_tb_bwd_kernel(int B, int T_, int V, co
   }
 }
 
+// rows (t*B + b) with t >= lengths[b] := 0 (16-byte stores; ld in bytes, a multiple of 16)
+__global__ __launch_bounds__(256) void mask_rows_tb_kernel(int T_, int B, long ld_bytes, const int* lengths, char* buf) {
+  const long cpr = ld_bytes / 16, n = (long)T_ * B * cpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / cpr;
+    const int t = (int)(row / B), b = (int)(row - (long)t * B);
+    if (t >= lengths[b]) *reinterpret_cast<uint4*>(buf + row * ld_bytes + (i - row * cpr) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 // one thread per (row, 8-column group): 16-byte stores
 __global__ __launch_bounds__(256) void onehot_tb_kernel(const int64_t* idx, int B, int L, int nrows, bf16_t* out, long ld) {
   const int gpr = (int)(ld / 8);
@@ -789,6 +799,14 @@ int mvae_ce_loss_bwd(int dtype, int B, int T, int V, const float* logits, int64_
   else if (dtype == MVAE_BF16)
     hipLaunchKernelGGL((ce_tb_bwd_kernel<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, B, T, V, logits, (long)ldl, x, pad, loss2, grad_out, dy_ext, (bf16_t*)dl, (long)ldd);
   else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_mask_rows_tb(int dtype, int T, int B, int64_t ld, const int32_t* lengths, void* buf, void* stream) {
+  if (!lengths || !buf || T < 1 || B < 1 || ld < 1 || (dtype != MVAE_F32 && dtype != MVAE_BF16)) return MVAE_ERR_INVALID;
+  const long ldb = (long)ld * (dtype == MVAE_BF16 ? 2 : 4);
+  if ((ldb % 16) || (reinterpret_cast<uintptr_t>(buf) & 15)) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(mask_rows_tb_kernel, dim3(grid_for((long)T * B * (ldb / 16))), dim3(256), 0, (hipStream_t)stream, T, B, ldb, lengths, (char*)buf);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

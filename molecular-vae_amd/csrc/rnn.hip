@@ -1265,12 +1265,13 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     static const Cand cand[5] = {{128, 128, 1, 1281}, {256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
     for (int c = 0; c < 5 && !nsplit; ++c) {
       if (B % cand[c].bm || (cand[c].ns == 4 && (4 * H) % (2 * ke))) continue;
+      if (drop && cand[c].ns == 1) continue;      // the unsplit wave-specialised instantiation carries no dropout factor (DROP = false): never with a mask
       const long wgs = (long)(B / cand[c].bm) * (H / cand[c].bn) * cand[c].ns * NL;
       if (split_knob == cand[c].key || (split_knob == 1 && wgs >= (cand[c].ns == 1 ? 256 : 192))) { BM = cand[c].bm; BN = cand[c].bn; nsplit = cand[c].ns; }
     }
     // small stacks (GRU 3 x 512 at B = 128: 96 workgroups of (128 x 64, 4)) still beat the fused 64 x 64 tiles: 15 vs 25 us / launch
     if (!nsplit && split_knob == 1 && (4 * H) % (2 * ke) == 0 && (long)(B / 128) * (H / 64) * 4 * NL >= 64) { BM = 128; BN = 64; nsplit = 4; }
-    if (nsplit > 1 && d->split_ws_bytes < (size_t)NL * nsplit * B * H * sizeof(float)) nsplit = 0;
+    if (nsplit > 1 && d->split_ws_bytes < (size_t)NL * nsplit * B * H * sizeof(float)) { nsplit = 0; BM = 64; BN = 64; }   // caller's scratch too small: the fused 64 x 64 tile
     // Short contractions (GRU 3 x 512: 6H = 3072 columns): a fused 64 x 64 tile streams under 1 MB, and with the pipelined straight-line
     // epilogue one fused launch beats the split GEMM + element-wise pair once it has about a workgroup per CU: MOSES B = 1024 6.99 -> 6.64,
     // B = 512 5.58 -> 5.10 ms / step (B <= 256: 4.43 vs 4.48, the split pair stays); 4 x 1024 (8H = 8192 columns, 2 MB per tile) never.
@@ -1348,6 +1349,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     }
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n * (split ? nsplit : 1)), block(256);
+    if (big_fused && drop) return MVAE_ERR_UNSUPPORTED;      // (excluded above; an unhandled combination must never run silently)
     if (big_fused) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0>)); continue; }
     if (split) {
       if (BM == 256) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 256, 128, 3, true, false, 1>)); block = dim3(256); }

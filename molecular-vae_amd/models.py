@@ -149,7 +149,10 @@ class _Workspace:
 
 
 _LDPAD = 64   # elements added to power-of-two leading dimensions of the big recurrent operands
-_DYK = 128    # K extent (two 64-deep K-steps, so that the 4-way split backward can halve it) of the output-gradient product, see MolDecoder
+def _dyk(n_out):
+    """K extent of the output-gradient product dy = dl . W_out (see MolDecoder): the class / vocabulary count rounded up to whole pairs of
+    64-deep K-steps (so that the 4-way split backward can halve it)."""
+    return _pad(n_out, 128)
 
 
 def _require_cuda(dev, what):
@@ -551,8 +554,8 @@ class MolDecoder(nn.Module):
             Cv = om.out_features
             Cp = _pad(Cv, 8)
             P["Wout"] = ws.get("Wout", (Cv, H), dt, dev)
-            # bf16: W_out^T zero-padded to _DYK columns -- the backward contracts the logit gradients with it inside the top LSTM cell
-            P["WoutT"] = ws.get("WoutT", (H, _DYK if dt == torch.bfloat16 else Cp), dt, dev)
+            # bf16: W_out^T zero-padded to _dyk(C) columns -- the backward contracts the logit gradients with it inside the top LSTM cell
+            P["WoutT"] = ws.get("WoutT", (H, _dyk(Cv) if dt == torch.bfloat16 else Cp), dt, dev)
             ops.cast_transpose(om.weight, Cv, H, dst=P["Wout"], dstT=P["WoutT"])
         self._pack_key, self._packed = key, P
         return P
@@ -636,7 +639,7 @@ class _DecoderFn(torch.autograd.Function):
         # K8 backward
         # bf16 (and a hidden size the LDS-direct loop serves): the top LSTM cell contracts dl . W_out itself (no [T, B, H] fp32 dy tensor)
         fuse_dy = dt == torch.bfloat16 and (4 * H) % 64 == 0
-        ldl = _DYK if fuse_dy else Cp               # pad columns are allocated zero and never written
+        ldl = _dyk(Cv) if fuse_dy else Cp           # pad columns are allocated zero and never written
         dl = W("dl", (TB + 8, ldl), dt)[:TB]        # +8 rows: the TN tile reads 256-byte row segments past the last row
         dlT = None
         if dt != torch.bfloat16:
@@ -653,7 +656,7 @@ class _DecoderFn(torch.autograd.Function):
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [P["ldwT"]] * NL, P["WihT"], [P["ldwT"]] * NL, dy, H, hs, ldh, cs, gates,
                     dG, dstate, ldg=ldg, tag="dec_lstm_bwd", dy_a=(dl if fuse_dy else None), dy_w=(P["WoutT"] if fuse_dy else None),
-                    dy_k=(_DYK if fuse_dy else 0))
+                    dy_k=(_dyk(Cv) if fuse_dy else 0))
 
         def weight_grads(part):
             """Everything that only produces parameter gradients (nothing on the path to dz): output head + LSTM weights.

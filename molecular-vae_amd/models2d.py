@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .models import LinearWeights, Conv1dWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _DYK
+from .models import LinearWeights, Conv1dWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _dyk
 from .mosesvae import _kmajor_gemm
 
 SEQ, VOCAB, HID, HP, NLAY = 120, 35, 501, 512, 3
@@ -129,7 +129,7 @@ class VAE(nn.Module):
             P["Wx0T"] = ws.get("Wx0T", (4, 4 * HP), f32, dev); ops.cast_transpose(P["Wx0"], 4 * HP, 4, dstT=P["Wx0T"])
             Cp = _pad(VOCAB, 8)
             w3p = torch.zeros(VOCAB, HP, device=dev); w3p[:, :HID].copy_(self.fc3.weight)
-            P["Wfc"] = ws.get("Wfc", (VOCAB, ldw), dt, dev); P["WfcT"] = ws.get("WfcT", (HP, _DYK if dt == torch.bfloat16 else Cp), dt, dev)
+            P["Wfc"] = ws.get("Wfc", (VOCAB, ldw), dt, dev); P["WfcT"] = ws.get("WfcT", (HP, _dyk(VOCAB) if dt == torch.bfloat16 else Cp), dt, dev)
             ops.cast_transpose(w3p, VOCAB, HP, dst=P["Wfc"], dstT=P["WfcT"])
         self._pack_key, self._packed = key, P
         return P
@@ -229,7 +229,7 @@ class _Models2dFn(torch.autograd.Function):
         # ---- fc3 + softmax
         drecon = drecon.contiguous().float()
         fuse_dy = dt == torch.bfloat16 and (4 * HP) % 64 == 0   # the top GRU cell contracts dl . W_fc3 itself
-        ldl = _DYK if fuse_dy else Cp
+        ldl = _dyk(VOCAB) if fuse_dy else Cp
         dl = W("dl", (TB + 8, ldl), dt)[:TB]
         ops.softmax_tb_bwd(recon, drecon, dl, None, B, SEQ, VOCAB)
         hsx = [W(f"hsx{l}", (SEQ + 1, B, ldh), dt) for l in range(NLAY)]
@@ -247,7 +247,7 @@ class _Models2dFn(torch.autograd.Function):
         dstate = [W(f"dstate{l}", (2, B, HP)) for l in range(NLAY)]
         ops.rnn_bwd(L.CELL_GRU, dt, SEQ, B, HP, P["WhhT"], [P["ldwT"]] * NLAY, P["WihT"], [P["ldwT"]] * NLAY, dy, HP,
                     [h[1:] for h in hsx], ldh, None, gates, dG, dstate, ldg=ldg, h0=[h[0] for h in hsx], ldh0=ldh, tag="m2d_gru_bwd",
-                    dy_a=(dl if fuse_dy else None), dy_w=(P["WfcT"] if fuse_dy else None), dy_k=(_DYK if fuse_dy else 0))
+                    dy_a=(dl if fuse_dy else None), dy_w=(P["WfcT"] if fuse_dy else None), dy_k=(_dyk(VOCAB) if fuse_dy else 0))
         s4 = W("s4", (4 * HP,))
         tmp = W("dw_gru", (4 * HP, HP))
         for l in range(NLAY):

@@ -10,9 +10,10 @@ Train mode (``model.train()``): the decoder GRU's inter-layer dropout (``d_dropo
 kernels -- layer l+1 reads ``h^l * keep / (1 - p)`` -- with the keep mask generated on device by a counter-based hash from an explicit
 seed (``forward(..., drop_seed=)``; by default drawn from torch's CPU generator, so ``torch.manual_seed`` makes a run reproducible) or
 injected (``forward(..., drop_mask=)``: uint8 ``[layers-1, T, B, H]``; the parity tests inject the mask the reference drew).  ``eval()``
-computes the deterministic network.  Under data parallelism (an initialised ``torch.distributed`` group) the token mean of the
-reconstruction loss (mosesvae.py:193-197) is taken over the GLOBAL number of non-pad targets (``dp_global_token_mean``), so that the
-all-reduced gradient equals the single-process gradient of the global batch.
+computes the deterministic network.  Under data parallelism (an initialised ``torch.distributed`` group) a TRAINING forward (train mode,
+gradients enabled) takes the token mean of the reconstruction loss (mosesvae.py:193-197) over the GLOBAL number of non-pad targets
+(``dp_global_token_mean``, one 4-byte all-reduce on ``dp_group``), so that the all-reduced gradient equals the single-process gradient of
+the global batch; eval / no_grad forwards never communicate.
 """
 import torch
 import torch.distributed as dist
@@ -20,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _DYK
+from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _dyk
 from .vocab import PaddedBatch, pad_batch
 
 
@@ -65,6 +66,7 @@ class VAE(nn.Module):
         self.vae = nn.ModuleList([self.x_emb, self.encoder, self.decoder])
         self.d_z, self.d_dropout = d_z, d_dropout
         self.dp_global_token_mean = True     # DP: normalise the CE by the global non-pad token count (see module docstring)
+        self.dp_group = None                 # process group of that reduction (None: the default group); moses_train_step sets it from the optimiser's GradSync
         self.last_drop_seed = None           # seed of the most recent train-mode forward (None: eval / injected mask)
         self.compute_dtype = dtype
         self._ws = _Workspace()
@@ -114,11 +116,14 @@ class VAE(nn.Module):
                 drop = (float(self.d_dropout), seed, None)
                 self.last_drop_seed = seed
         kl, recon, z, logvar, y, ntok = _MosesFn.apply(self, x_pad, len_t, eps.contiguous().float(), drop, *self._plist())
-        if self.dp_global_token_mean and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # Data-parallel TRAINING steps only (train mode, gradients enabled): every rank of `dp_group` makes this call once per step.  Evaluation,
+        # no_grad encoding and rank-0-only validation stay collective-free (a collective only some ranks reach would deadlock).
+        if (self.dp_global_token_mean and self.training and torch.is_grad_enabled() and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size(self.dp_group) > 1):
             # local mean = num_r / cnt_r; the gradient all-reduce averages over ranks, so scale to  num_r * world / sum_r cnt_r
             tot = ntok.detach().clone()
-            dist.all_reduce(tot)
-            recon = recon * (ntok.detach() * dist.get_world_size() / tot)
+            dist.all_reduce(tot, group=self.dp_group)
+            recon = recon * (ntok.detach() * dist.get_world_size(self.dp_group) / tot)
         return kl, recon, z, logvar, x_pad, y
 
     def forward_encoder(self, x, eps=None):
@@ -227,7 +232,7 @@ class VAE(nn.Module):
                 ops.cast_transpose(seq[2].weight, seq[2].out_features, seq[2].in_features, dstT=P[n + "_W2T"])
             P["WlatT"] = ws.get("WlatT", (dz, Hd), f32, dev); ops.cast_transpose(self.decoder_lat.weight, Hd, dz, dstT=P["WlatT"])
             Vp8 = _pad(V, 8)
-            P["Wfc"] = ws.get("Wfc", (V, Hd + _LDPAD), dt, dev); P["WfcT"] = ws.get("WfcT", (Hd, _DYK if dt == torch.bfloat16 else Vp8), dt, dev)
+            P["Wfc"] = ws.get("Wfc", (V, Hd + _LDPAD), dt, dev); P["WfcT"] = ws.get("WfcT", (Hd, _dyk(V) if dt == torch.bfloat16 else Vp8), dt, dev)
             ops.cast_transpose(self.decoder_fc.weight, V, Hd, dst=P["Wfc"], dstT=P["WfcT"])
         self._pack_key, self._packed = key, P
         return P
@@ -348,7 +353,7 @@ class _MosesFn(torch.autograd.Function):
         # ---------------- decoder_fc + cross-entropy
         y_tb, loss2 = W("y_tb", (TB, V)), W("loss2", (2,))
         fuse_dy = dt == torch.bfloat16 and (4 * Hd) % 64 == 0   # the top GRU cell contracts dl . W_fc itself (pad / finished positions: zero rows in dl)
-        ldl = _DYK if fuse_dy else Vp8
+        ldl = _dyk(V) if fuse_dy else Vp8
         dl = W("dl", (TB + 8, ldl), dt)[:TB]
         if drecon is None:
             drecon = torch.zeros((), device=dev)
@@ -357,6 +362,11 @@ class _MosesFn(torch.autograd.Function):
         out_seq = hsx_d[-1][1:].reshape(TB, ldh_d)
         _kmajor_gemm(ws, "fc", dl, ldl, V, out_seq, ldh_d, Hd, TB, grads["decoder_fc.weight"], dev)
         dbp = W("dbfc_p", (Vp8,)); ops.colsum_t(dl, TB, Vp8, dbp, ldx=ldl); grads["decoder_fc.bias"].copy_(dbp[:V])
+        if fuse_dy and dy_ext is not None:
+            # an external gradient w.r.t. the returned logits sits in dl at finished positions too (it counts for decoder_fc.bias, above); the
+            # padded output carries no gradient back to h there (pad_packed_sequence, mosesvae.py:189), and the top cell contracts dl AS IS:
+            # clear those rows first.  (The CE's own gradient is zero there already: the target is pad.)
+            ops.mask_rows_tb(dl, T, B, lengths)
         dyd = None
         if not fuse_dy:
             dyd = W("dy_dec", (TB, Hd)); ops.gemm_nt(dl, P["WfcT"], dyd, TB, Hd, Vp8)
@@ -371,7 +381,7 @@ class _MosesFn(torch.autograd.Function):
                     lengths=lengths, dh0=dh0,
                     drop_mask=(None if drop is None or drop[2] is None else [drop[2][l] for l in range(NL - 1)]),
                     drop_p=(drop[0] if drop else 0.0), drop_seed=(drop[1] if drop else 0), tag="moses_dec_bwd",
-                    dy_a=(dl if fuse_dy else None), dy_w=(P["WfcT"] if fuse_dy else None), dy_k=(_DYK if fuse_dy else 0))
+                    dy_a=(dl if fuse_dy else None), dy_w=(P["WfcT"] if fuse_dy else None), dy_k=(_dyk(V) if fuse_dy else 0))
         hd = [W(f"dec_hd{l}", (T, B, ldh_d), dt) for l in range(NL - 1)] if drop is not None else None
         s4 = W("dec_s4", (4 * Hd,))
         for l in range(NL):

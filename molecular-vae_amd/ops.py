@@ -207,6 +207,11 @@ def relu_bwd(dy, y):
     check(L.load().mvae_relu_bwd(dy.numel(), ptr(dy), ptr(y), stream_ptr()), "mvae_relu_bwd")
 
 
+def mask_rows_tb(buf, T, B, lengths):
+    """rows (t*B + b) with t >= lengths[b] of the time-major [T*B, ld] buffer := 0."""
+    check(L.load().mvae_mask_rows_tb(dt_code(buf.dtype), T, B, buf.stride(0), ptr(lengths), ptr(buf), stream_ptr()), "mvae_mask_rows_tb")
+
+
 def permute102(inp, out, T, B, V):
     check(L.load().mvae_permute102(T, B, V, ptr(inp), ptr(out), stream_ptr()), "mvae_permute102")
 

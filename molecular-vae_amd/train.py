@@ -363,6 +363,9 @@ def moses_train_step(model, optimizer, kl_weight, batch, eps=None):
     backward, ``clip_grad_norm_(50)`` (the optimiser's ``max_grad_norm``) and ``Adam.step()`` -- without the per-step ``.item()``
     syncs.  Returns device scalars ``(loss, kl, recon)``."""
     optimizer.zero_grad(set_to_none=True)
+    sync = getattr(optimizer, "grad_sync", None)
+    if sync is not None and hasattr(model, "dp_group"):
+        model.dp_group = sync.group          # the CE's global token count is reduced over the ranks the gradients are reduced over
     kl_loss, recon_loss, _, _, _, _ = model(batch) if eps is None else model(batch, eps=eps)
     loss = kl_weight * kl_loss + recon_loss
     loss.backward()

@@ -188,11 +188,13 @@ def test_two_rank_moses_data_parallel_uses_the_global_token_mean(tmp_path):
             assert abs(x - y) <= 2e-5 * abs(x), (k, ra[k], rb[k])
 
 
-@pytest.mark.parametrize("dtype", ["f32"])
-def test_two_rank_data_parallel_equals_single_process(tmp_path, dtype):
+@pytest.mark.parametrize("dtype,tol", [("f32", dict(loss=2e-6, psum=2e-6, gnorm=2e-6)), ("bf16", dict(loss=5e-4, psum=1e-5, gnorm=3e-2))])
+def test_two_rank_data_parallel_equals_single_process(tmp_path, dtype, tol):
     """The PRODUCT path under data parallelism: 4 optimiser steps of the full-size model, (a) one process, global batch 2b;
     (b) two ranks (fresh child processes sharing this GPU, gloo), b each, GradSync with the early all-reduce started from backward.
-    Losses, parameter sums and pre-clip gradient norms must agree to fp32 re-association noise (<= 2e-6 relative)."""
+    Losses, parameter sums and pre-clip gradient norms must agree to fp32 re-association noise (<= 2e-6 relative) in the exact-f32 mode;
+    in the bf16 mode (the bench configuration) the two layouts pick different tiles, whose fp32 summation orders round to different bf16
+    values now and then: loss within 5e-4, gradient norm within 3 %."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = os.path.join(ROOT, "tests", "dp_equiv.py")
@@ -206,4 +208,4 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path, dtype):
     assert rb["world"] == 2 and rb["early_ranges"] == 2 * 4
     for k in ("loss", "psum", "gnorm"):
         for x, y in zip(ra[k], rb[k]):
-            assert abs(x - y) <= 2e-6 * abs(x), (k, ra[k], rb[k])
+            assert abs(x - y) <= tol[k] * abs(x), (k, ra[k], rb[k])
