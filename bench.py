@@ -13,12 +13,16 @@ init under manual_seed(42), bf16 decoder-LSTM storage / fp32 accumulate + fp32 m
 Inputs are resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline     -- dominant kernel family (decoder LSTM wavefront forward step, MFMA bound): algorithmic FLOPs per launch /
-                  average launch duration measured live with HIP events on the launching stream.
+  roofline     -- the decoder LSTM wavefront step kernel with the larger share of the step (MFMA bound; at B = 1024 the fused backward step):
+                  algorithmic FLOPs per launch / average launch duration measured live with HIP events on the launching stream; the other
+                  direction's kernel under `other`.
   cpu_baseline -- oracle/torch_ref.py (the reference architecture on stock torch.nn, CPU) timed on this host's cores on a bounded
                   sample (rank 0, N = 1 only).
   secondary    -- N = 1 only: the same step at configs[1] (B=512 bf16), at the per-rank shape of configs[2] (b=128 bf16, with its own
-                  roofline object) and in the exact-f32 parity mode (B=1024), each on fewer steps.
+                  roofline object), in the exact-f32 parity mode (B=1024), the mosesvae.VAE step of configs[3] (B=1024) and the long-sequence
+                  stress of configs[4] (L=256, C=64, B=2048, with the GB/s of its HBM-bound kernels), each on fewer steps.
+  comm         -- N > 1 only: allreduce_exposed_ms (HIP-event time the main stream waited for the gradient all-reduce in the optimiser
+                  step), the world size and backend torch.distributed reported, gradient bytes per step.
 `--model moses` / `--model models2d` bench the mosesvae.VAE path (configs[3]) and the models2d.VAE variant the same way.
 """
 import argparse
@@ -164,19 +168,32 @@ class MolVaeWorkload:
         return out
 
     def roofline(self, tag_ms, dtype):
+        """`kernel` is the wavefront step kernel with the larger share of the step's time -- at B >= 1024 the fused backward step
+        (lstm_step_bwd_kernel<bf16,128,128,4,WS>: one launch per diagonal), at smaller batches the backward PAIR (split GEMM launch +
+        element-wise launch) or the forward step, whichever is slower; the other direction's figures stand beside it (`other`)."""
         fwd_f, bwd_f, n_launch = lstm_step_flops(self.B, self.L)
         fwd_us = 1e3 * tag_ms.get("dec_lstm_fwd", float("nan")) / n_launch
         bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
         peak = BF16_DENSE_PEAK_TFLOPS if dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-        # Dominant SINGLE kernel: the forward wavefront step.  The backward step is two kernels per launch (partial-tile GEMM + element-wise
-        # gate-derivative kernel), each smaller than the forward step; its pair time is reported alongside.
-        ach = fwd_f / (fwd_us * 1e-6) / 1e12
-        ach_bwd = bwd_f / (bwd_us * 1e-6) / 1e12
-        return dict(bound="mfma", kernel="lstm_step_fwd_kernel", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    traffic=pmc_traffic("lstm_step_fwd", self.B, dtype),
-                    launches_per_pass=n_launch, avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
-                    flops_per_launch=dict(lstm_step_fwd=fwd_f, lstm_step_bwd=bwd_f), bwd_pair_tflops=round(ach_bwd, 2),
-                    bwd_pair_frac=round(ach_bwd / peak, 4), hbm_bound_kernels=self.hbm_kernels(tag_ms))
+        fused_bwd = dtype == "bf16" and self.B >= 1024 and self.B % 128 == 0
+        leg = {"fwd": dict(kernel=("lstm_step_fwd_gm_kernel" if dtype == "bf16" and (self.B >= 1024 or self.B <= 128) else "lstm_step_fwd_kernel"),
+                           us=fwd_us, flops=fwd_f, pmc_key="lstm_step_fwd"),
+               "bwd": dict(kernel=("lstm_step_bwd_kernel (fused gate-derivative epilogue)" if fused_bwd or dtype != "bf16" else
+                                   "lstm_step_bwd_kernel + lstm_bwd_epi_kernel (launch pair)"), us=bwd_us, flops=bwd_f, pmc_key="lstm_step_bwd")}
+        for v in leg.values():
+            v["tflops"] = v["flops"] / (v["us"] * 1e-6) / 1e12
+        dom = "bwd" if not (bwd_us < fwd_us) else "fwd"
+        oth = "fwd" if dom == "bwd" else "bwd"
+        d, o = leg[dom], leg[oth]
+        traffic, src = pmc_traffic(d["pmc_key"], self.B, dtype)
+        return dict(bound="mfma", kernel=d["kernel"], achieved=round(d["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(d["tflops"] / peak, 4),
+                    traffic=traffic, traffic_source=src, launches_per_pass=n_launch,
+                    share_of_step_ms=round(d["us"] * n_launch * 1e-3, 3),
+                    avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
+                    flops_per_launch=dict(lstm_step_fwd=fwd_f, lstm_step_bwd=bwd_f),
+                    other=dict(kernel=o["kernel"], achieved=round(o["tflops"], 2), frac=round(o["tflops"] / peak, 4),
+                               share_of_step_ms=round(o["us"] * n_launch * 1e-3, 3)),
+                    hbm_bound_kernels=self.hbm_kernels(tag_ms))
 
     def config(self, world):
         return dict(workload=self.name, per_gpu_batch=self.B, global_batch=self.B * world, seq_len=self.L, vocab=self.C, latent=LATENT,
@@ -184,20 +201,21 @@ class MolVaeWorkload:
 
 
 def pmc_traffic(kernel_key, B, dtype):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, KB -> bytes; collected off-line with tests/collect_pmc.sh on the same kernel at the same shape --
-    bench.py cannot run the profiler on itself); null when no profile of this shape exists."""
+    """(HBM bytes per launch, source) of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, KB -> bytes).  NOT from this run: collected off-line with tests/collect_pmc.sh on a T = 16 micro-benchmark of
+    the same kernel at the same batch (bench.py cannot run the profiler on itself); (None, None) when no profile of this shape exists."""
     if dtype != "bf16":
-        return None
-    for name in (f"r02_pmc_kernels_T16_B{B}.json", f"r01_v9_pmc_kernels_T16_B{B}.json"):
+        return None, None
+    for name in (f"r03_pmc_kernels_T16_B{B}.json", f"r02_pmc_kernels_T16_B{B}.json", f"r01_v9_pmc_kernels_T16_B{B}.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
         for k, v in pm.items():
             if kernel_key in k and "hbm_read_MB_corrected" in v and "hbm_write_MB" in v:
-                return int((v["hbm_read_MB_corrected"] + v["hbm_write_MB"]) * 1024 * 1024)
-    return None
+                return (int((v["hbm_read_MB_corrected"] + v["hbm_write_MB"]) * 1024 * 1024),
+                        f"profiles/{name}: off-line PMC passes over a T=16 micro-benchmark of this kernel at B={B}, full-grid launches")
+    return None, None
 
 
 def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB):
@@ -245,9 +263,17 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
     tag_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in prof.items()}
     roof = wl.roofline(tag_ms, dtype)
     roof["phase_ms"] = {k: round(v, 3) for k, v in tag_ms.items()}
+    comm = None
+    if world > 1:
+        # time the main stream spent blocked on the gradient all-reduce in FusedAdam.step (HIP events around start_rest + wait): what the
+        # overlap with backward did NOT hide.  MAX over ranks, like the step time.
+        t = torch.tensor([tag_ms.get("dp_allreduce_exposed", 0.0)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm = dict(allreduce_exposed_ms=round(float(t), 3), world_size_reported=dist.get_world_size(), backend=dist.get_backend(),
+                    gradient_bytes=4 * getattr(wl, "n_params", 0), early_ranges_per_step=(sync.stats["early_ranges"] / max(1, steps + warmup)) if sync else 0)
     roof["whole_step_tflops"] = round(wl.flops_per_step() * steps / dt / 1e12, 2)
     res = dict(value=round(B * world * steps / dt, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup, dtype=dtype,
-               final_loss=round(float(loss), 6), roofline=roof, config=wl.config(world))
+               final_loss=round(float(loss), 6), roofline=roof, config=wl.config(world), comm=comm)
     del wl
     ops.release_caches()
     torch.cuda.empty_cache()
@@ -299,15 +325,22 @@ def main():
     out = dict(metric=metric, value=main_res["value"], unit="molecules/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=main_res["ms_per_step"], higher_is_better=True, scaling=scaling, vs_baseline=None, dtype=args.dtype,
                data="synthetic", config=cfg, roofline=main_res["roofline"])
+    if main_res.get("comm") is not None:
+        out["comm"] = main_res["comm"]
 
     if (world == 1 and args.model == "molvae" and not args.no_secondary and args.batch == 0 and args.dtype == "bf16"
             and (args.seq_len, args.vocab) == (L_SEQ, VOCAB)):
+        # every BASELINE.json config gets a number on this line: configs[1] (B=512), the per-rank shape of configs[2] (b=128), the exact-f32
+        # parity mode, configs[3] (mosesvae.VAE, B=1024) and configs[4] (L=256, C=64, B=2048 with the GB/s of its HBM-bound kernels)
         sec = {}
-        for label, b, dt_, st, wu in (("configs1_B512_bf16", 512, "bf16", 10, 3), ("configs2_per_rank_b128_bf16", 128, "bf16", 20, 5),
-                                      ("parity_mode_B1024_f32", args.global_batch, "f32", 3, 1)):
-            r = measure("molvae", b, dt_, st, wu, dev, rank, 1, None, label)
+        for label, mdl, b, dt_, st, wu, Lq, Cq in (("configs1_B512_bf16", "molvae", 512, "bf16", 10, 3, L_SEQ, VOCAB),
+                                                   ("configs2_per_rank_b128_bf16", "molvae", 128, "bf16", 20, 5, L_SEQ, VOCAB),
+                                                   ("parity_mode_B1024_f32", "molvae", args.global_batch, "f32", 10, 2, L_SEQ, VOCAB),
+                                                   ("configs3_moses_B1024", "moses", 1024, "bf16", 20, 5, L_SEQ, VOCAB),
+                                                   ("configs4_L256_C64_B2048", "molvae", 2048, "bf16", 5, 2, 256, 64)):
+            r = measure(mdl, b, dt_, st, wu, dev, rank, 1, None, label, Lq, Cq)
             sec[label] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=st, warmup=wu, dtype=dt_,
-                              per_gpu_batch=b, final_loss=r["final_loss"], roofline=r["roofline"])
+                              per_gpu_batch=b, final_loss=r["final_loss"], roofline=r["roofline"], workload=r["config"]["workload"])
         out["secondary"] = sec
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -760,12 +760,65 @@ __device__ __forceinline__ void bwd_cell_finish(const StepArgsB& p, const StepTa
   }
 }
 
+// Packed (unconverted) operands of one group: what a wave can hold across the whole main loop without touching them -- a bf16 -> fp32
+// conversion at the load would make the wave wait for the data right there.  32 registers per group (40 with dy).
+struct BwdRaw { float4 dci[2], dy[2]; uint4 g[4], c, cp; };
+template <bool HAS_DY>
+__device__ __forceinline__ void bwd_raw_load(const StepArgsB& p, const StepTaskB& q, int row, int j8, BwdRaw& r) {
+  const int H = p.H;
+  const bf16_t* gates = reinterpret_cast<const bf16_t*>(q.gates);
+  const long o = (long)row * H + j8;
+  const float* dsrc = (q.dc_in ? q.dc_in : q.dc_out) + o;
+  r.dci[0] = *reinterpret_cast<const float4*>(dsrc); r.dci[1] = *reinterpret_cast<const float4*>(dsrc + 4);
+  if (gates == nullptr) return;                   // GRU pseudo-cell t = -1 (workgroup-uniform): only the carry is read
+  if constexpr (HAS_DY) {
+    const float* ysrc = q.dy ? q.dy + (long)row * q.dy_ld + j8 : q.dc_out + o;
+    r.dy[0] = *reinterpret_cast<const float4*>(ysrc); r.dy[1] = *reinterpret_cast<const float4*>(ysrc + 4);
+  }
+  const bf16_t* g4 = gates + (long)row * 4 * H + j8;
+  r.g[0] = *reinterpret_cast<const uint4*>(g4); r.g[1] = *reinterpret_cast<const uint4*>(g4 + H);
+  r.g[2] = *reinterpret_cast<const uint4*>(g4 + 2 * H); r.g[3] = *reinterpret_cast<const uint4*>(g4 + 3 * H);
+  if (p.cell == MVAE_CELL_LSTM) {
+    const bf16_t* cs = reinterpret_cast<const bf16_t*>(q.c);
+    const bf16_t* csp = reinterpret_cast<const bf16_t*>(q.c_prev);
+    r.c = *reinterpret_cast<const uint4*>(cs + o);
+    r.cp = *reinterpret_cast<const uint4*>((csp ? csp : cs) + o);
+  } else {
+    r.cp = *reinterpret_cast<const uint4*>(q.h_prev ? reinterpret_cast<const bf16_t*>(q.h_prev) + (long)row * q.ldhp + j8 : g4);
+  }
+}
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
+}
+template <bool HAS_DY>
+__device__ __forceinline__ void bwd_raw_unpack(const BwdRaw& r, BwdOps& o) {
+  o.dci[0] = r.dci[0].x; o.dci[1] = r.dci[0].y; o.dci[2] = r.dci[0].z; o.dci[3] = r.dci[0].w;
+  o.dci[4] = r.dci[1].x; o.dci[5] = r.dci[1].y; o.dci[6] = r.dci[1].z; o.dci[7] = r.dci[1].w;
+  if constexpr (HAS_DY) {
+    o.dy[0] = r.dy[0].x; o.dy[1] = r.dy[0].y; o.dy[2] = r.dy[0].z; o.dy[3] = r.dy[0].w;
+    o.dy[4] = r.dy[1].x; o.dy[5] = r.dy[1].y; o.dy[6] = r.dy[1].z; o.dy[7] = r.dy[1].w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.dy[e] = 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) unpack8(r.g[g], o.g[g]);
+  unpack8(r.c, o.c); unpack8(r.cp, o.cp);
+}
+
 // DROP: instantiations that can apply the inter-layer dropout factor inside the fused (single-launch) form -- a separate template
 // flag so that the hot instantiations carry no trace of it (with both forms in one body hipcc moved the LDS-DMA descriptors to scratch).
 // SPLITMODE: 1 = instantiation launched in split mode only (stores partial tiles; carries no gate-derivative epilogue), 0 = fused only
 // (no partial-tile code), -1 = decided at run time.  The step kernels of the small batches run ~20 us: what an instantiation does not
 // need is kept out of its code (the same kernel with both epilogues in it: +0.8 us per launch at b = 128).
-template <typename T, int BM, int BN, int NBUF, bool WS = false, bool DROP = false, int SPLITMODE = -1>
+// PREF (fused wave-specialised form only): 1 / 2 = the epilogue's operands are PREFETCHED (2: no cell of the stack has a dy tensor -- the
+// output gradient enters as a product, so that load does not exist).  The loader waves request the saved gates / cell states / carried
+// gradient of ALL their groups before the first LDS-DMA and hold them, packed, in registers they do not otherwise use (the counted vmcnt
+// waits of the ring stay valid: loads retire in issue order and these are the oldest); the consumer waves request their first group there
+// and the other three right after the main loop, in front of the staging barrier.  No load sits behind a store any more.
+template <typename T, int BM, int BN, int NBUF, bool WS = false, bool DROP = false, int SPLITMODE = -1, int PREF = 0>
 __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB p) {
   constexpr bool PIPE = NBUF > 0;
   constexpr int NTHR = WS ? 512 : 256;
@@ -793,6 +846,78 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
 #pragma unroll
     for (int n = 0; n < NI; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (PREF != 0) {
+    static_assert(WS && NBUF > 0 && SPLITMODE == 0 && !DROP && sizeof(T) == 2, "prefetching form: fused, wave-specialised, bf16");
+    constexpr bool HAS_DY = PREF == 1;
+    constexpr int SN = BN + 4, GPR = BN / 8, RPI = NTHR / GPR, NIT = BM / RPI;
+    static_assert(BM % RPI == 0, "whole row groups per thread");
+    // host guarantees (rnn_bwd_impl, big_fused): B % BM == 0, H % BN == 0, 16-byte aligned everything -- every group is whole and in range
+    PipeSeg<BM, BN> s0, s1;
+    {
+      const uint32_t lda = (uint32_t)q.lda0 * 2u, ldw = (uint32_t)q.ldw0 * 2u;
+      auto offA = [&](int r) -> uint32_t { return (uint32_t)(m0 + r) * lda; };
+      auto offB = [&](int r) -> uint32_t { return (uint32_t)(n0 + r) * ldw; };
+      pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)H * ldw, offA, offB, p.gru3 ? 3 * H : q.K0, tid & 255);
+      if (p.gru3) { s0.hole_st = (int)(2 * H * 2 / KB); s0.hole_bytes = (uint32_t)H * 2u; }
+    }
+    {
+      const uint32_t lda = (uint32_t)q.lda1 * 2u, ldw = (uint32_t)q.ldw1 * 2u;
+      auto offA = [&](int r) -> uint32_t { return (uint32_t)(m0 + r) * lda; };
+      auto offB = [&](int r) -> uint32_t { return (uint32_t)(n0 + r) * ldw; };
+      pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, (p.gru3 && !q.seg1_full) ? 3 * H : q.K1, tid & 255);
+    }
+    const int nk = s0.nk + s1.nk;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g8 = tid % GPR, j8 = n0 + g8 * 8, row0 = m0 + tid / GPR;
+    float* stg = reinterpret_cast<float*>(smem);
+    BwdRaw raw[NIT];
+    auto finish_all = [&]() {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int lrow = tid / GPR + it * RPI;
+        const float* sp_ = stg + lrow * SN + g8 * 8;
+        const float4 a = *reinterpret_cast<const float4*>(sp_), b = *reinterpret_cast<const float4*>(sp_ + 4);
+        float dh[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        BwdOps o;
+        bwd_raw_unpack<HAS_DY>(raw[it], o);
+        bwd_cell_finish<T, true>(p, q, m0 + lrow, j8, 8, true, o, dh);
+      }
+    };
+#ifdef MVAE_TUNING
+    const bool run_main = !(p.dbg & 2);
+#else
+    constexpr bool run_main = true;
+#endif
+    if (wv >= 4) {
+      // ---- loader waves: every group's operands first (oldest in the memory queue), then the ring
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) bwd_raw_load<HAS_DY>(p, q, row0 + it * RPI, j8, raw[it]);
+      if (nk > 0 && run_main) { tile_gemm_ws_loader<T, BM, BN, NBUF>(smem, s0, s1, wv - 4); ws_barrier(); }
+#ifdef MVAE_TUNING
+      if (p.dbg & 1) return;
+#endif
+      __syncthreads();
+      finish_all();
+    } else {
+      bwd_raw_load<HAS_DY>(p, q, row0, j8, raw[0]);
+      if (nk > 0 && run_main) { tile_gemm_ws_consumer<T, BM, BN, MI, NI, NBUF, NI, 0>(smem, nk, wm * WM, wn * WN, acc, lane); ws_barrier(); }
+#ifdef MVAE_TUNING
+      if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.dc_out[0] = 1.f; return; }
+#endif
+      const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[(wm * WM + i * 16 + lq * 4 + r) * SN + wn * WN + n * 16 + lr] = acc[i][n][r];
+#pragma unroll
+      for (int it = 1; it < NIT; ++it) bwd_raw_load<HAS_DY>(p, q, row0 + it * RPI, j8, raw[it]);
+      __syncthreads();
+      finish_all();
+    }
+    return;
+  }
   const bool fused_drop = DROP && q.drop && !p.split && q.A1 != nullptr;      // wave-uniform; compiled out unless DROP
   auto scale_drop = [&]() {                     // accumulator layout: row = 4 (lane >> 4) + r, column = lane & 15 of each 16 x 16 sub-tile
 #pragma unroll
@@ -1350,7 +1475,14 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     a.ntask = n;
     dim3 grid(n * a.tiles_m * a.tiles_n * (split ? nsplit : 1)), block(256);
     if (big_fused && drop) return MVAE_ERR_UNSUPPORTED;      // (excluded above; an unhandled combination must never run silently)
-    if (big_fused) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0>)); continue; }
+    if (big_fused) {
+      block = dim3(512);
+      const int pref = tune_int("MVAE_BWD_PREF", 1);           // 0: the round-2 form (operands requested inside the epilogue), A/B knob
+      if (!pref) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0>));
+      else if (d->dy) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0, 1>));
+      else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0, 2>));
+      continue;
+    }
     if (split) {
       if (BM == 256) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 256, 128, 3, true, false, 1>)); block = dim3(256); }
       else if (BN == 64) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true, false, 1>)); block = dim3(256); }

@@ -597,64 +597,74 @@ __device__ __forceinline__ void tile_gemm_ws_tn(char* smem, const PipeSegTN<MI>&
 
 // NT form of the wave-specialised loop (same contract as tile_gemm_pipe, 512 threads; s0 / s1 must have been initialised
 // with tid & 255, so that loader wave w + 4 issues the pieces wave w issues in the 256-thread form).
+// The two roles as separate functions (a caller that gives the roles different work around the loop -- the fused backward step, whose
+// loader waves hold prefetched epilogue operands in their otherwise idle registers -- branches ONCE on the wave index and calls one of them;
+// each must be followed by the closing ws_barrier() that tile_gemm_ws issues).
+template <typename T, int BM, int BN, int NBUF>
+__device__ __forceinline__ void tile_gemm_ws_loader(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int lwave) {
+  constexpr int LPS = (BM + BN) * 8 / 256;
+  static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
+  const int nk = s0.nk + s1.nk;
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s)
+    if (s < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, s, lwave);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>();
+    else wait_vmcnt<0>();
+    ws_barrier();                                                       // barrier(kt)
+    if (kt + NBUF - 1 < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, lwave);
+  }
+}
+template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT>
+__device__ __forceinline__ void tile_gemm_ws_consumer(char* smem, int nk, int arow0, int brow0, f32x4 (&acc)[MI][NI], int lane) {
+  constexpr int STAGE = (BM + BN) * KB;
+  static_assert(MI + NI <= 15, "lgkmcnt range");
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const int lr = lane & 15, lk = lane >> 4;
+  uint32_t a_lane[2], b_lane[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    a_lane[kk] = (uint32_t)swz(arow0 + lr, kk * 4 + lk);
+    b_lane[kk] = (uint32_t)swz(brow0 + lr, kk * 4 + lk) + BM * KB;
+  }
+  u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
+  ws_barrier();                                                         // barrier(0)
+  FragRead<0, MI, 16 * KB>::run(a0, lds0 + a_lane[0]);
+  FragReadB<0, NI, JS, BOUT>::run(b0, lds0 + b_lane[0]);
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
+    FragRead<0, MI, 16 * KB>::run(a1, st + a_lane[1]);
+    FragReadB<0, NI, JS, BOUT>::run(b1, st + b_lane[1]);
+    wait_lgkmcnt<MI + NI>();                                            // first half arrived, second half in flight
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        mma16<T>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
+    wait_lgkmcnt<0>();                                                  // every read of stage kt is done
+    if (kt + 1 < nk) {
+      ws_barrier();                                                     // barrier(kt + 1)
+      const uint32_t sn = lds0 + (uint32_t)(((kt + 1) % NBUF) * STAGE);
+      FragRead<0, MI, 16 * KB>::run(a0, sn + a_lane[0]);
+      FragReadB<0, NI, JS, BOUT>::run(b0, sn + b_lane[0]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        mma16<T>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
+  }
+}
+
 template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT>
 __device__ __forceinline__ void tile_gemm_ws(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int arow0, int brow0,
                                              f32x4 (&acc)[MI][NI], int tid) {
-  constexpr int STAGE = (BM + BN) * KB;
-  constexpr int LPS = (BM + BN) * 8 / 256;
-  static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
-  static_assert(MI + NI <= 15, "lgkmcnt range");
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = s0.nk + s1.nk;
   if (nk <= 0) return;
-  if (wave >= 4) {
-#pragma unroll
-    for (int s = 0; s < NBUF - 1; ++s)
-      if (s < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, s, wave - 4);
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>();
-      else wait_vmcnt<0>();
-      ws_barrier();                                                       // barrier(kt)
-      if (kt + NBUF - 1 < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, wave - 4);
-    }
-  } else {
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-    const int lr = lane & 15, lk = lane >> 4;
-    uint32_t a_lane[2], b_lane[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      a_lane[kk] = (uint32_t)swz(arow0 + lr, kk * 4 + lk);
-      b_lane[kk] = (uint32_t)swz(brow0 + lr, kk * 4 + lk) + BM * KB;
-    }
-    u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
-    ws_barrier();                                                         // barrier(0)
-    FragRead<0, MI, 16 * KB>::run(a0, lds0 + a_lane[0]);
-    FragReadB<0, NI, JS, BOUT>::run(b0, lds0 + b_lane[0]);
-    for (int kt = 0; kt < nk; ++kt) {
-      const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
-      FragRead<0, MI, 16 * KB>::run(a1, st + a_lane[1]);
-      FragReadB<0, NI, JS, BOUT>::run(b1, st + b_lane[1]);
-      wait_lgkmcnt<MI + NI>();                                            // first half arrived, second half in flight
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          mma16<T>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
-      wait_lgkmcnt<0>();                                                  // every read of stage kt is done
-      if (kt + 1 < nk) {
-        ws_barrier();                                                     // barrier(kt + 1)
-        const uint32_t sn = lds0 + (uint32_t)(((kt + 1) % NBUF) * STAGE);
-        FragRead<0, MI, 16 * KB>::run(a0, sn + a_lane[0]);
-        FragReadB<0, NI, JS, BOUT>::run(b0, sn + b_lane[0]);
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          mma16<T>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
-    }
-  }
+  if (wave >= 4) tile_gemm_ws_loader<T, BM, BN, NBUF>(smem, s0, s1, wave - 4);
+  else tile_gemm_ws_consumer<T, BM, BN, MI, NI, NBUF, JS, BOUT>(smem, nk, arow0, brow0, acc, lane);
   ws_barrier();
 }
 

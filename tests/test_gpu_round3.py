@@ -194,7 +194,8 @@ def test_moses_gradient_through_logits_stops_at_finished_positions(dtype):
     for k in grads[0]:
         if k == "decoder_fc.bias":
             want = grads[0][k] + w.sum((0, 1))
-            assert torch.allclose(grads[1][k], want, rtol=2e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-3 if dtype == torch.bfloat16 else 1e-5)
+            # bf16: dl (w included) is stored in bf16 before the column sum: ~200 terms of magnitude 1, each rounded to 8 bits
+            assert torch.allclose(grads[1][k], want, rtol=2e-2 if dtype == torch.bfloat16 else 1e-5, atol=0.15 if dtype == torch.bfloat16 else 1e-5)
         else:
             assert torch.equal(grads[0][k], grads[1][k]), k
     # and a gradient on VALID positions does go everywhere (the mask did not wipe it)
