@@ -24,6 +24,9 @@ ap.add_argument("--smi", default=None)
 ap.add_argument("-b", "--batch_size", default=128, type=int)                                # moses_train_distrib.py:177
 ap.add_argument("--epochs", default=100, type=int)
 ap.add_argument("--n_samples", default=1024, type=int)
+ap.add_argument("--n_synth", default=8192, type=int, help="size of the synthetic corpus when no --smi is given")
+ap.add_argument("--out_dir", default=".")
+ap.add_argument("--report", default=None, help="write a JSON summary (the per-epoch postfix dictionaries + samples) here")
 args = ap.parse_args()
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -36,8 +39,8 @@ if args.smi:
     smiles = D.load_smiles(args.smi)
 else:                                                    # synthetic MOSES-like corpus (no data ships with the reference)
     rs = np.random.RandomState(0)
-    alphabet = list("CNOSFcnos()=#123[]@H+-lBr")
-    smiles = ["".join(rs.choice(alphabet, size=int(np.clip(rs.normal(38, 8), 10, 57)))) for _ in range(8192)]
+    lens = np.clip(rs.normal(38, 8, size=args.n_synth), 10, 57).astype(int)
+    smiles = [D.synthetic_smiles(1, seed=1000 + i, lo=int(n), hi=int(n) + 1)[0] for i, n in enumerate(lens)]
 vocab = VC.OneHotVocab.from_data(smiles)                 # moses_train_distrib.py:166
 collate = VC.get_padded_collate_fn(vocab, pin_memory=True)
 sampler = mv.ShardedSampler(len(smiles), rank=rank, world=world, seed=0)
@@ -50,20 +53,26 @@ optimizer = mv.FusedAdam(model.parameters(), lr=3e-4, max_grad_norm=50.0, grad_s
 kl_annealer = mv.KLAnnealer(args.epochs)                                                     # :47-58, :185
 lr_annealer = mv.CosineAnnealingLRWithRestart(optimizer)                                     # :61-89, :195
 
+report = dict(vocab=len(vocab), n=len(smiles), epochs=[], samples=[])
 for epoch in range(args.epochs):
     sampler.set_epoch(epoch)
     kl_weight = kl_annealer(epoch)
     post = mv.moses_train_epoch(model, epoch, (b.to(dev) for b in loader), kl_weight, optimizer, log_every=100 if rank == 0 else 0)
     if rank == 0:                                        # :342-353
         print(post, flush=True)
-        torch.save(model.state_dict(), "trained_save.pt")
-        with open("vocab.pkl", "wb") as f:
+        report["epochs"].append(post)
+        torch.save(model.state_dict(), os.path.join(args.out_dir, "trained_save.pt"))
+        with open(os.path.join(args.out_dir, "vocab.pkl"), "wb") as f:
             pickle.dump(vocab, f)
         model.eval()
         res, _ = model.sample(min(args.n_samples, 64), max_len=60)
         model.train()
         for s in res[:5]:
             print("sample:", s)
+        report["samples"] = res[:16]
     lr_annealer.step()                                   # :355
+if rank == 0 and args.report:
+    import json
+    json.dump(report, open(args.report, "w"))
 if world > 1:
     torch.distributed.destroy_process_group()

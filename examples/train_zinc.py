@@ -24,6 +24,9 @@ ap.add_argument("--smi", default=None)
 ap.add_argument("--max_len", default=120, type=int)
 ap.add_argument("--epochs", default=1, type=int)
 ap.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int)    # moses_train_distrib.py:27
+ap.add_argument("--n_synth", default=4096, type=int, help="size of the synthetic corpus when no --smi is given")
+ap.add_argument("--out_dir", default=".", help="where the checkpoint goes")
+ap.add_argument("--report", default=None, help="write a JSON summary (per-epoch losses, molecules/s through the input pipeline) here")
 args = ap.parse_args()
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -34,10 +37,8 @@ if world > 1:
 
 if args.smi:
     smiles = [s for s in D.load_smiles(args.smi) if len(s) < args.max_len]
-else:                                               # synthetic corpus of the ZINC alphabet
-    rs = np.random.RandomState(0)
-    alphabet = list("CNOSFcnos()=#123[]@H+-lBr")
-    smiles = ["".join(rs.choice(alphabet, size=rs.randint(20, 60))) for _ in range(4096)]
+else:                                               # synthetic corpus of the ZINC alphabet (motif strings: learnable in one epoch)
+    smiles = D.synthetic_smiles(args.n_synth, seed=0)
 max_len = args.max_len
 vocab = D.build_vocab(smiles, max_len)              # train.py:45-60, sorted
 charset = {i: c for c, i in vocab.items()}
@@ -52,17 +53,26 @@ optimizer = mv.FusedAdam(model.parameters(), lr=0.0008, max_grad_norm=3.0, grad_
 scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, "min", factor=0.9, patience=10, threshold=1e-3, cooldown=5)
 loss_function = mv.make_loss_function(max_len)
 
+report = dict(batch_size=args.batch_size, n_train=len(train_ds), n_test=len(test_ds), vocab=len(vocab), epochs=[])
+ckpt_path = os.path.join(args.out_dir, f"save_{args.batch_size}_{args.optimizer}_{args.latent_size}.pt")
 for epoch in range(1, args.epochs + 1):
     model.train()
-    total, n = torch.zeros((), device=dev), 0
+    total, n, nb = torch.zeros((), device=dev), 0, 0
+    first = None
+    t_beg, t_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_beg.record()
     for batch_idx, (data, ohe) in enumerate(train_ds.batches(args.batch_size, epoch=epoch, seed=0, rank=rank, world=world)):
         loss = mv.train_step(model, optimizer, loss_function, data, ohe)           # train.py:95-104
-        total += loss; n += data.shape[0]
+        total += loss; n += data.shape[0]; nb += 1
+        if first is None:
+            first = loss
         if batch_idx % 100 == 0 and rank == 0:
             with torch.no_grad():
                 recon, _, _ = model(data)
                 acc = mv.exact_match_accuracy(recon, data)                          # train.py:109-113
             print(f"train: {epoch} / {batch_idx}\t{float(loss):.4f}\tacc {float(acc):.3f}", flush=True)
+    t_end.record(); torch.cuda.synchronize()
+    epoch_ms = t_beg.elapsed_time(t_end)
     # test(epoch), train.py:120-153: forward-only (no saved state is written under no_grad), every sequence of the shard (drop_last=False)
     val, acc = mv.evaluate(model, loss_function, test_ds.batches(args.batch_size, shuffle=False, rank=rank, world=world, drop_last=False))
     if world > 1:                                        # every rank must take the same ReduceLROnPlateau decision
@@ -71,7 +81,12 @@ for epoch in range(1, args.epochs + 1):
     scheduler.step(val)                                  # train.py:165
     if rank == 0:
         print(f"epoch {epoch}: train {float(total) / max(n, 1):.5f}  val {val:.5f}  acc {acc:.4f}  lr {optimizer.param_groups[0]['lr']:.2e}", flush=True)
-        mv.save_checkpoint(f"save_{args.batch_size}_{args.optimizer}_{args.latent_size}.pt", model, optimizer, epoch, charset, max_len,
-                           latent_size=args.latent_size)                             # train.py:170-177
+        mv.save_checkpoint(ckpt_path, model, optimizer, epoch, charset, max_len, latent_size=args.latent_size)      # train.py:170-177
+        report["epochs"].append(dict(epoch=epoch, first_batch_loss=float(first), mean_batch_loss=float(total) / max(nb, 1), val_loss=val, val_acc=acc,
+                                     molecules_per_s_through_pipeline=n * world / (epoch_ms * 1e-3)))
+if rank == 0 and args.report:
+    import json
+    report["checkpoint"] = ckpt_path
+    json.dump(report, open(args.report, "w"))
 if world > 1:
     torch.distributed.destroy_process_group()

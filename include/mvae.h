@@ -287,8 +287,9 @@ int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const flo
 /* ---------------------------------------------------------------------------------------------------------
  * Output head (K8; models.py:157 Linear + nn.Softmax() over the class axis of the [B*L, C] view,
  * models.py:43-50).  logits [(t*B+b), ldl] fp32 -> recon [B, L, C] fp32 probabilities.
- * Backward: dlogits = p * (drecon - sum_c drecon*p), written in dtype as dl [(t*B+b), ldd] (zero padded
- * columns C..ldd-1) and, when dlT != NULL, transposed dlT [C][ldT] (column t*B+b).
+ * Backward: dlogits = p * (drecon - sum_c drecon*p), written in dtype as dl [(t*B+b), ldd] and, when dlT != NULL, transposed
+ * dlT [C][ldT] (column t*B+b).  Columns C .. C8-1 (C8 = C rounded up to 8) of dl are written as zero; the K-padding columns C8 .. ldd-1
+ * are the CALLER's to keep zero (allocate the buffer zeroed: this call may or may not touch them -- the tiled bf16 form does not).
  */
 int mvae_softmax_tb_fwd(int B, int L, int C, const float* logits, int64_t ldl, float* recon, void* stream);
 int mvae_softmax_tb_bwd(int dtype, int B, int L, int C, const float* recon, const float* drecon,
@@ -297,8 +298,9 @@ int mvae_softmax_tb_bwd(int dtype, int B, int L, int C, const float* recon, cons
 /* ---------------------------------------------------------------------------------------------------------
  * ELBO of train.py:31-38, verbatim: max_len * BCELoss(mean)(recon, x) - 0.5*mean(1 + mu - logvar^2 - exp(mu))
  * (binary CE on the softmax outputs with the log clamp at -100; mu / logvar swapped in the KL term, as the
- * reference computes it).  loss_out[0] = total, [1] = xent term, [2] = KL term.  Deterministic two-stage
- * reduction; ws >= mvae_bce_kl_loss_workspace().
+ * reference computes it).  loss_out[0] = total, [1] = xent term, [2] = KL term.  ONE launch: per-block partial sums, a ticket counter, and
+ * the block drawing the last ticket sums the partials in a fixed order (deterministic).  ws >= mvae_bce_kl_loss_workspace() bytes, 4-byte
+ * aligned, private to this call site; its LAST 16 BYTES (the ticket) must be zero before the first call -- every call leaves them zero again.
  * Backward: drecon = g*(max_len/n)*(p - t)/max(p(1-p),1e-12); dmu = g*(-0.5/m)(1 - exp(mu));
  * dlogvar = g*(0.5/m)*2*logvar, with g = *grad_out (device scalar) or 1 when NULL.
  */

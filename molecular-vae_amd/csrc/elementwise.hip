@@ -4,6 +4,7 @@
 // are bitwise reproducible run to run.
 #include "common.hpp"
 #include "kernels.hpp"
+#include <stdlib.h>
 
 static inline int grid_for(long n, int per_block = 256, int cap = 2048) {
   long b = (n + per_block - 1) / per_block;
@@ -385,15 +386,304 @@ __global__ __launch_bounds__(256) void softmax_tb_bwd_kernel(int B, int L, int C
   }
 }
 
+// ---- tiled forms (round 3).  The head's two layouts differ in ROW ORDER: logits / dl are time-major (row t*B + b, what the recurrent
+// kernels produce and consume), recon / drecon batch-major ([B, L, C], what the reference returns).  A workgroup owns a tile of TT time
+// steps x BB batch rows, ONE ROW PER THREAD: on the time-major side the BB rows of a time step are one contiguous run of BB*C floats, on
+// the batch-major side the TT rows of a molecule are one contiguous run of TT*C floats, so both sides move as flat 16-byte streams through
+// an LDS image [TT*BB][C|1] (odd row stride: the per-row passes of 64 lanes hit 64 different banks).  No lane idles for C < 64, no shuffle
+// reductions, and the transposition costs no uncoalesced access.  (One wave per row -- the kernels above -- left 45 % of the lanes idle at
+// C = 35 and paid two 6-step shuffle reductions per 140-byte row: 0.15 / 0.25 of the HBM roof at the headline shape.)
+// Tile walker.  One side of a tile is `nruns` runs of contiguous memory (time-major side: one run per time step = the tile's batch rows;
+// batch-major side: one run per molecule = the tile's time steps), each run `rows_in` rows of `W` units (floats, or 16-byte chunks), moved in
+// pieces of `UPP` units; `rq` = pieces per run.  A thread visits pieces Q = tid, tid + NT, ...  The walker keeps (run, piece in run) and
+// (row in run, unit in row) of the current piece and advances all four by the fixed stride WITHOUT a division (runtime-divisor integer
+// divisions cost ~25 instructions each; two per 16-byte piece had made the first tiled form ALU-bound).
+struct TileWalk {
+  int run, q, row, c;           // current piece: run index, piece inside the run, row inside the run, unit inside the row (of its FIRST unit)
+  int d_run, d_q, d_row, d_c;   // stride decomposed the same way
+  int rq, W, rows_in;
+  __device__ __forceinline__ void init(int Q0, int stride, int rq_, int W_, int rows_in_, int upp) {
+    rq = rq_; W = W_; rows_in = rows_in_;
+    run = Q0 / rq; q = Q0 - run * rq;
+    const int f = q * upp; row = f / W; c = f - row * W;
+    d_run = stride / rq; d_q = stride - d_run * rq;
+    const int g = d_q * upp; d_row = g / W; d_c = g - d_row * W;
+  }
+  __device__ __forceinline__ void step() {
+    run += d_run; q += d_q; row += d_row; c += d_c;
+    if (c >= W) { c -= W; ++row; }
+    if (q >= rq) { q -= rq; ++run; row -= rows_in; }
+  }
+};
+
+// LDS image [TT_*BB_][C|1] (odd stride: the per-row passes of 64 lanes hit 64 banks).  Phase 1 fills it in TIME-major row order (row =
+// ti * BB_ + bi); phase 2 (one row per thread, the row held in registers) computes and writes the result back in BATCH-major row order (row =
+// bi * TT_ + ti) after a barrier -- the transposition happens there, in place; phase 3 streams the image out.  Every global access is a
+// 16-byte piece of a contiguous run, all of a batch's loads are in flight before the first is used.
+template <int TT_, int BB_, int CMAX>
+__global__ __launch_bounds__(TT_ * BB_) void softmax_tile_fwd_kernel(int B, int L, int C, const float* __restrict__ logits, float* __restrict__ recon) {
+  extern __shared__ __attribute__((aligned(16))) float sm_t[];
+  constexpr int ROWS = TT_ * BB_, U = 8;
+  const int CP = C | 1;
+  const int tiles_b = (B + BB_ - 1) / BB_;
+  const int tb = blockIdx.x % tiles_b, tt = blockIdx.x / tiles_b;
+  const int b0 = tb * BB_, t0 = tt * TT_;
+  const int nb = (B - b0 < BB_) ? (B - b0) : BB_, nt = (L - t0 < TT_) ? (L - t0) : TT_;
+  const int tid = threadIdx.x;
+  const int run = nb * C;
+  if (((run & 3) == 0) && ((((long)B * C) & 3) == 0) && ((((long)b0 * C) & 3) == 0)) {
+    const int rq = run >> 2, total = nt * rq;
+    TileWalk w; w.init(tid, ROWS, rq, C, nb, 4);
+    for (int Q0 = tid; Q0 < total; Q0 += ROWS * U) {
+      float4 v[U]; int lrow[U], lc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (Q0 + u * ROWS < total) {
+          v[u] = *reinterpret_cast<const float4*>(logits + ((long)(t0 + w.run) * B + b0) * C + 4 * w.q);
+          lrow[u] = w.run * BB_ + w.row; lc[u] = w.c;
+          w.step();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (Q0 + u * ROWS < total) {
+          const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          int r = lrow[u], c = lc[u];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { sm_t[r * CP + c] = e[j]; if (++c == C) { c = 0; ++r; } }
+        }
+      }
+    }
+  } else {
+    for (int q = tid; q < nt * run; q += ROWS) { const int ti = q / run, f = q - ti * run, r = f / C, c = f - r * C; sm_t[(ti * BB_ + r) * CP + c] = logits[((long)(t0 + ti) * B + b0) * C + f]; }
+  }
+  __syncthreads();
+  const int ti_ = tid / BB_, bi_ = tid - ti_ * BB_;
+  const bool live = ti_ < nt && bi_ < nb;
+  float x[CMAX];
+  if (live) {
+    const float* rowp = sm_t + tid * CP;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) x[c] = (c < C) ? rowp[c] : -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) mx = fmaxf(mx, x[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { x[c] = expf(x[c] - mx); sum += x[c]; }        // exp(-inf) = 0 for the columns past C
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) x[c] *= inv;
+  }
+  __syncthreads();                                                                  // every row is in registers: the image may be permuted
+  if (live) {
+    float* rowo = sm_t + (bi_ * TT_ + ti_) * CP;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) rowo[c] = x[c];
+  }
+  __syncthreads();
+  const int runo = nt * C;
+  if (((runo & 3) == 0) && ((((long)L * C) & 3) == 0) && ((((long)t0 * C) & 3) == 0)) {
+    const int rq = runo >> 2, total = nb * rq;
+    TileWalk w; w.init(tid, ROWS, rq, C, nt, 4);
+    for (int Q = tid; Q < total; Q += ROWS) {
+      int r = w.run * TT_ + w.row, c = w.c;
+      float e[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { e[j] = sm_t[r * CP + c]; if (++c == C) { c = 0; ++r; } }
+      *reinterpret_cast<float4*>(recon + ((long)(b0 + w.run) * L + t0) * C + 4 * w.q) = make_float4(e[0], e[1], e[2], e[3]);
+      w.step();
+    }
+  } else {
+    for (int q = tid; q < nb * runo; q += ROWS) { const int bi = q / runo, f = q - bi * runo, ti = f / C, c = f - ti * C; recon[((long)(b0 + bi) * L + t0) * C + f] = sm_t[(bi * TT_ + ti) * CP + c]; }
+  }
+}
+
+// backward, bf16 dl: dl[(t*B + b), c] = p (dp - sum_c dp p) for c < C, zero for C <= c < C8 = C rounded up to 8; columns >= C8 are NOT written.
+// Same three phases the other way round: in batch-major (row = bi * TT_ + ti), out time-major (row = ti * BB_ + bi).
+template <int TT_, int BB_, int CMAX>
+__global__ __launch_bounds__(TT_ * BB_) void softmax_tile_bwd_kernel(int B, int L, int C, const float* __restrict__ recon, const float* __restrict__ drecon,
+                                                                     bf16_t* __restrict__ dl, long ldd) {
+  extern __shared__ __attribute__((aligned(16))) float sm_t[];
+  constexpr int ROWS = TT_ * BB_, U = 4;
+  const int CP = C | 1;
+  float* P = sm_t; float* D = sm_t + ROWS * CP;
+  const int tiles_b = (B + BB_ - 1) / BB_;
+  const int tb = blockIdx.x % tiles_b, tt = blockIdx.x / tiles_b;
+  const int b0 = tb * BB_, t0 = tt * TT_;
+  const int nb = (B - b0 < BB_) ? (B - b0) : BB_, nt = (L - t0 < TT_) ? (L - t0) : TT_;
+  const int tid = threadIdx.x;
+  const int runi = nt * C;
+  if (((runi & 3) == 0) && ((((long)L * C) & 3) == 0) && ((((long)t0 * C) & 3) == 0)) {
+    const int rq = runi >> 2, total = nb * rq;
+    TileWalk w; w.init(tid, ROWS, rq, C, nt, 4);
+    for (int Q0 = tid; Q0 < total; Q0 += ROWS * U) {
+      float4 vp[U], vd[U]; int lrow[U], lc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (Q0 + u * ROWS < total) {
+          const long src = ((long)(b0 + w.run) * L + t0) * C + 4 * w.q;
+          vp[u] = *reinterpret_cast<const float4*>(recon + src); vd[u] = *reinterpret_cast<const float4*>(drecon + src);
+          lrow[u] = w.run * TT_ + w.row; lc[u] = w.c;
+          w.step();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (Q0 + u * ROWS < total) {
+          const float ep[4] = {vp[u].x, vp[u].y, vp[u].z, vp[u].w}, ed[4] = {vd[u].x, vd[u].y, vd[u].z, vd[u].w};
+          int r = lrow[u], c = lc[u];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { P[r * CP + c] = ep[j]; D[r * CP + c] = ed[j]; if (++c == C) { c = 0; ++r; } }
+        }
+      }
+    }
+  } else {
+    for (int q = tid; q < nb * runi; q += ROWS) {
+      const int bi = q / runi, f = q - bi * runi, ti = f / C, c = f - ti * C;
+      const long src = ((long)(b0 + bi) * L + t0) * C + f;
+      P[(bi * TT_ + ti) * CP + c] = recon[src]; D[(bi * TT_ + ti) * CP + c] = drecon[src];
+    }
+  }
+  __syncthreads();
+  const int bi_ = tid / TT_, ti_ = tid - bi_ * TT_;            // the row this thread owns, in the order phase 1 wrote it
+  const bool live = ti_ < nt && bi_ < nb;
+  float pv[CMAX];
+  if (live) {
+    const float* pr = P + tid * CP; const float* dr = D + tid * CP;
+    float dv[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { pv[c] = (c < C) ? pr[c] : 0.f; dv[c] = (c < C) ? dr[c] : 0.f; }
+    float sdot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) sdot += dv[c] * pv[c];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) pv[c] = pv[c] * (dv[c] - sdot);
+  }
+  __syncthreads();
+  if (live) {
+    float* po = P + (ti_ * BB_ + bi_) * CP;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) po[c] = pv[c];
+  }
+  __syncthreads();
+  // time-major side out: run = one time step = nb rows of c8n 16-byte chunks (row stride ldd in memory: the runs are not dense there, so
+  // the walker's piece unit is a chunk and every piece carries its own row)
+  const int c8n = (C + 7) >> 3, rq = nb * c8n, total = nt * rq;
+  TileWalk w; w.init(tid, ROWS, rq, c8n, nb, 1);
+  for (int Q = tid; Q < total; Q += ROWS) {
+    const float* pr = P + (w.run * BB_ + w.row) * CP + w.c * 8;
+    uint32_t wd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = w.c * 8 + 2 * j;
+      const float lo = (c < C) ? pr[2 * j] : 0.f, hi = (c + 1 < C) ? pr[2 * j + 1] : 0.f;
+      wd[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+    *reinterpret_cast<uint4*>(dl + ((long)(t0 + w.run) * B + b0 + w.row) * ldd + w.c * 8) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    w.step();
+  }
+}
+
+// ---- class counts that are a multiple of 4 with 16-byte aligned rows (BASELINE configs[4]: C = 64): no LDS at all.  A row is C / 4
+// float4 pieces = LPR lanes (a power of two >= C / 4), so a wave owns 64 / LPR consecutive rows, the two row reductions are log2(LPR)
+// shuffle steps inside the lane group, and every access is a 16-byte piece of a contiguous row on both sides.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+constexpr int SV_RPT = 4;      // rows per lane group and thread: all their loads go out before the first reduction
+template <int LPR>
+__global__ __launch_bounds__(256) void softmax_vec_fwd_kernel(int B, int L, int C, const float* __restrict__ logits, float* __restrict__ recon) {
+  constexpr int RPW = 64 / LPR;                                   // rows per wave and pass
+  const long rows = (long)B * L;
+  const int lane = threadIdx.x & 63, g = lane / LPR, j = lane - g * LPR;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (RPW * SV_RPT) + g;
+  const bool on = 4 * j < C;
+  float4 x[SV_RPT];
+#pragma unroll
+  for (int r = 0; r < SV_RPT; ++r) {
+    const long row = row0 + r * RPW;
+    x[r] = (on && row < rows) ? *reinterpret_cast<const float4*>(logits + row * C + 4 * j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  }
+#pragma unroll
+  for (int r = 0; r < SV_RPT; ++r) {
+    const long row = row0 + r * RPW;
+    const float mx = group_max<LPR>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
+    float4 e = make_float4(expf(x[r].x - mx), expf(x[r].y - mx), expf(x[r].z - mx), expf(x[r].w - mx));
+    const float inv = 1.f / group_sum<LPR>((e.x + e.y) + (e.z + e.w));
+    if (on && row < rows) {
+      const int t = (int)(row / B), b = (int)(row - (long)t * B);
+      *reinterpret_cast<float4*>(recon + ((long)b * L + t) * C + 4 * j) = make_float4(e.x * inv, e.y * inv, e.z * inv, e.w * inv);
+    }
+  }
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void softmax_vec_bwd_kernel(int B, int L, int C, const float* __restrict__ recon, const float* __restrict__ drecon,
+                                                              bf16_t* __restrict__ dl, long ldd) {
+  constexpr int RPW = 64 / LPR;
+  const long rows = (long)B * L;
+  const int lane = threadIdx.x & 63, g = lane / LPR, j = lane - g * LPR;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (RPW * SV_RPT) + g;   // time-major row index t * B + b
+  const bool on = 4 * j < C;
+  float4 p[SV_RPT], d[SV_RPT];
+#pragma unroll
+  for (int r = 0; r < SV_RPT; ++r) {
+    const long row = row0 + r * RPW;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on && row < rows) {
+      const int t = (int)(row / B), b = (int)(row - (long)t * B);
+      const long src = ((long)b * L + t) * C + 4 * j;
+      p[r] = *reinterpret_cast<const float4*>(recon + src); d[r] = *reinterpret_cast<const float4*>(drecon + src);
+    } else { p[r] = z; d[r] = z; }
+  }
+#pragma unroll
+  for (int r = 0; r < SV_RPT; ++r) {
+    const long row = row0 + r * RPW;
+    const float sdot = group_sum<LPR>((p[r].x * d[r].x + p[r].y * d[r].y) + (p[r].z * d[r].z + p[r].w * d[r].w));
+    if (on && row < rows) {
+      const float v0 = p[r].x * (d[r].x - sdot), v1 = p[r].y * (d[r].y - sdot), v2 = p[r].z * (d[r].z - sdot), v3 = p[r].w * (d[r].w - sdot);
+      uint2 w;
+      w.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16); w.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+      *reinterpret_cast<uint2*>(dl + row * ldd + 4 * j) = w;            // C % 4 == 0: the row's C columns exactly (no chunk padding needed when C % 8 == 0)
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- ELBO (train.py:31-38)
 constexpr int LOSS_BLOCKS = 2048;
+// log(p) and log1p(-p) on v_log_f32 (log2, 1 ulp): the libm forms (~25 instructions each, both evaluated for nearly every wave because a
+// one-hot row mixes t = 0 and t = 1 lanes) had made this "HBM-bound" kernel ALU-bound: 33 us for 37 MB.  log1p(x) = x log(1 + x) / ((1 + x) - 1)
+// keeps full relative accuracy for small x (Kahan); p == 0 / p == 1 give -inf and are clamped at -100 like BCELoss does.
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float fast_log1m(float p) {               // log(1 - p)
+  const float u = 1.f - p, d = u - 1.f;
+  return d == 0.f ? -p : fast_log(u) * (-p) * __builtin_amdgcn_rcpf(d);
+}
 __device__ __forceinline__ float bce_term(float p, float t) {
-  const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);   // BCELoss clamps both logs at -100
+  // BCELoss clamps both logs at -100.  Hard targets (the one-hot block: every t is 0 or 1) need only ONE of the two logarithms -- same value
+  // as the general form (the other term is multiplied by an exact zero).
+  if (t == 0.f) return fmaxf(fast_log1m(p), -100.f);
+  if (t == 1.f) return fmaxf(fast_log(p), -100.f);
+  const float lp = fmaxf(fast_log(p), -100.f), l1p = fmaxf(fast_log1m(p), -100.f);
   return t * lp + (1.f - t) * l1p;
 }
-__global__ __launch_bounds__(256) void bce_kl_partial_kernel(long n, const float* recon, const float* target, long m, const float* mu,
-                                                             const float* logvar, float* partial) {
+// ONE launch: every block writes its (xent, kl) partial sums, takes a ticket, and the block that draws the last ticket adds the partials up in
+// a fixed order (bitwise reproducible) and writes the three loss values.  `ticket` lives behind the partials in the caller's workspace: zero
+// before the first call, reset to zero by the finishing block (so zero again before the next).  Hand-off across XCDs (per-XCD L2s are not
+// coherent): every handed-off value is a device-scope (sc1) store drained with vmcnt(0) before the ticket, and a device-scope load after it.
+__global__ __launch_bounds__(256) void bce_kl_fused_kernel(long n, const float* recon, const float* target, long m, const float* mu,
+                                                           const float* logvar, float max_len, float* partial, unsigned int* ticket, float* out) {
   __shared__ float red[4];
+  __shared__ int s_last;
   float a = 0.f, k = 0.f;
   const long n4 = ((reinterpret_cast<uintptr_t>(recon) | reinterpret_cast<uintptr_t>(target)) & 15) ? 0 : n / 4;    // 16-byte vector part
   const float4* r4 = reinterpret_cast<const float4*>(recon);
@@ -409,16 +699,28 @@ __global__ __launch_bounds__(256) void bce_kl_partial_kernel(long n, const float
   }
   a = block_sum_256(a, red);
   k = block_sum_256(k, red);
-  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = k; }
-}
-__global__ __launch_bounds__(64) void bce_kl_final_kernel(int nblocks, const float* partial, long n, long m, float max_len, float* out) {
-  float a = 0.f, k = 0.f;
-  for (int i = threadIdx.x; i < nblocks; i += 64) { a += partial[2 * i]; k += partial[2 * i + 1]; }
-  a = wave_sum(a); k = wave_sum(k);
   if (threadIdx.x == 0) {
-    const float xent = max_len * (a / (float)n);
-    const float kl = -0.5f * (k / (float)m);
+    // my two partials as device-scope (sc1, write-through) stores, drained before my ticket; no agent-scope FENCE here: on gfx950 that is a
+    // write-back of every dirty line of this XCD's L2 (the recon tensor the softmax has just written), once per block -- 69 us instead of 20
+    __hip_atomic_store(partial + 2 * blockIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(partial + 2 * blockIdx.x + 1, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float sa = 0.f, sk = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {                     // device-scope (sc1) loads: past this CU's L1 and this XCD's L2
+    sa += __hip_atomic_load(partial + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sk += __hip_atomic_load(partial + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  sa = block_sum_256(sa, red);
+  sk = block_sum_256(sk, red);
+  if (threadIdx.x == 0) {
+    const float xent = max_len * (sa / (float)n);
+    const float kl = -0.5f * (sk / (float)m);
     out[0] = xent + kl; out[1] = xent; out[2] = kl;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call (stream order)
   }
 }
 __global__ __launch_bounds__(256) void bce_kl_bwd_kernel(long n, const float* recon, const float* target, long m, const float* mu,
@@ -829,11 +1131,44 @@ int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const flo
   return MVAE_OK;
 }
 
+static bool softmax_tiled_ok() { const char* e = getenv("MVAE_SOFTMAX_TILED"); return !e || atoi(e) != 0; }
 int mvae_softmax_tb_fwd(int B, int L, int C, const float* logits, int64_t ldl, float* recon, void* stream) {
   if (!logits || !recon || B < 1 || L < 1 || C < 1) return MVAE_ERR_INVALID;
   const long rows = (long)B * L;
   if (C > 64 * SM_CPL) return MVAE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(softmax_tb_fwd_kernel, dim3((unsigned)((rows + 4 * SM_ROWS - 1) / (4 * SM_ROWS))), dim3(256), 0, (hipStream_t)stream, B, L, C, logits, ldl, recon);
+  hipStream_t st = (hipStream_t)stream;
+  if (ldl == C && softmax_tiled_ok() && (C % 8) == 0 && C >= 16 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(recon)) & 15) == 0) {
+    // rows are whole 16-byte pieces: the register-only form
+    const int lpr = C <= 32 ? 8 : C <= 64 ? 16 : 32, rpb = 4 * (64 / lpr) * SV_RPT;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (lpr == 8) hipLaunchKernelGGL((softmax_vec_fwd_kernel<8>), grid, dim3(256), 0, st, B, L, C, logits, recon);
+    else if (lpr == 16) hipLaunchKernelGGL((softmax_vec_fwd_kernel<16>), grid, dim3(256), 0, st, B, L, C, logits, recon);
+    else hipLaunchKernelGGL((softmax_vec_fwd_kernel<32>), grid, dim3(256), 0, st, B, L, C, logits, recon);
+    MVAE_CHECK_HIP(hipGetLastError());
+    return MVAE_OK;
+  }
+  if (ldl == C && softmax_tiled_ok() && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(recon)) & 15) == 0) {
+    // tiled form: densely packed logits (what MolDecoder produces); 16 x 16 tiles (256 threads) up to 40 classes, 8 x 16 beyond (LDS)
+    static bool attr_set = false;
+    if (!attr_set) {
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_tile_fwd_kernel<16, 16, 40>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_tile_fwd_kernel<8, 16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_tile_fwd_kernel<8, 16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    const int CP = C | 1;
+    if (C <= 40) {
+      const unsigned grid = (unsigned)(((B + 15) / 16) * ((L + 15) / 16));
+      hipLaunchKernelGGL((softmax_tile_fwd_kernel<16, 16, 40>), dim3(grid), dim3(256), (size_t)256 * CP * sizeof(float), st, B, L, C, logits, recon);
+    } else {
+      const unsigned grid = (unsigned)(((B + 15) / 16) * ((L + 7) / 8));
+      if (C <= 64) hipLaunchKernelGGL((softmax_tile_fwd_kernel<8, 16, 64>), dim3(grid), dim3(128), (size_t)128 * CP * sizeof(float), st, B, L, C, logits, recon);
+      else hipLaunchKernelGGL((softmax_tile_fwd_kernel<8, 16, 128>), dim3(grid), dim3(128), (size_t)128 * CP * sizeof(float), st, B, L, C, logits, recon);
+    }
+    MVAE_CHECK_HIP(hipGetLastError());
+    return MVAE_OK;
+  }
+  hipLaunchKernelGGL(softmax_tb_fwd_kernel, dim3((unsigned)((rows + 4 * SM_ROWS - 1) / (4 * SM_ROWS))), dim3(256), 0, st, B, L, C, logits, ldl, recon);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
@@ -843,6 +1178,37 @@ int mvae_softmax_tb_bwd(int dtype, int B, int L, int C, const float* recon, cons
   const long rows = (long)B * L;
   hipStream_t st = (hipStream_t)stream;
   if (C > 64 * SM_CPL || ldd > 64 * SM_CPL) return MVAE_ERR_UNSUPPORTED;
+  if (dtype == MVAE_BF16 && !dlT && softmax_tiled_ok() && (C % 8) == 0 && C >= 16 && (ldd % 8) == 0 &&
+      ((reinterpret_cast<uintptr_t>(recon) | reinterpret_cast<uintptr_t>(drecon) | reinterpret_cast<uintptr_t>(dl)) & 15) == 0) {
+    const int lpr = C <= 32 ? 8 : C <= 64 ? 16 : 32, rpb = 4 * (64 / lpr) * SV_RPT;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (lpr == 8) hipLaunchKernelGGL((softmax_vec_bwd_kernel<8>), grid, dim3(256), 0, st, B, L, C, recon, drecon, (bf16_t*)dl, (long)ldd);
+    else if (lpr == 16) hipLaunchKernelGGL((softmax_vec_bwd_kernel<16>), grid, dim3(256), 0, st, B, L, C, recon, drecon, (bf16_t*)dl, (long)ldd);
+    else hipLaunchKernelGGL((softmax_vec_bwd_kernel<32>), grid, dim3(256), 0, st, B, L, C, recon, drecon, (bf16_t*)dl, (long)ldd);
+    MVAE_CHECK_HIP(hipGetLastError());
+    return MVAE_OK;
+  }
+  if (dtype == MVAE_BF16 && !dlT && softmax_tiled_ok() && (ldd % 8) == 0 && ldd >= ((C + 7) & ~7) &&
+      ((reinterpret_cast<uintptr_t>(recon) | reinterpret_cast<uintptr_t>(drecon) | reinterpret_cast<uintptr_t>(dl)) & 15) == 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_tile_bwd_kernel<16, 16, 40>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_tile_bwd_kernel<8, 16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_tile_bwd_kernel<8, 16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    const int CP = C | 1;
+    if (C <= 40) {
+      const unsigned grid = (unsigned)(((B + 15) / 16) * ((L + 15) / 16));
+      hipLaunchKernelGGL((softmax_tile_bwd_kernel<16, 16, 40>), dim3(grid), dim3(256), (size_t)2 * 256 * CP * sizeof(float), st, B, L, C, recon, drecon, (bf16_t*)dl, (long)ldd);
+    } else {
+      const unsigned grid = (unsigned)(((B + 15) / 16) * ((L + 7) / 8));
+      if (C <= 64) hipLaunchKernelGGL((softmax_tile_bwd_kernel<8, 16, 64>), dim3(grid), dim3(128), (size_t)2 * 128 * CP * sizeof(float), st, B, L, C, recon, drecon, (bf16_t*)dl, (long)ldd);
+      else hipLaunchKernelGGL((softmax_tile_bwd_kernel<8, 16, 128>), dim3(grid), dim3(128), (size_t)2 * 128 * CP * sizeof(float), st, B, L, C, recon, drecon, (bf16_t*)dl, (long)ldd);
+    }
+    MVAE_CHECK_HIP(hipGetLastError());
+    return MVAE_OK;
+  }
   const dim3 sgrid((unsigned)((rows + 4 * SM_ROWS - 1) / (4 * SM_ROWS)));
   if (dtype == MVAE_F32)
     hipLaunchKernelGGL((softmax_tb_bwd_kernel<float>), sgrid, dim3(256), 0, st, B, L, C, recon, drecon, (float*)dl, ldd, (float*)dlT, ldT);
@@ -853,14 +1219,19 @@ int mvae_softmax_tb_bwd(int dtype, int B, int L, int C, const float* recon, cons
   return MVAE_OK;
 }
 
-size_t mvae_bce_kl_loss_workspace(int64_t, int64_t) { return (size_t)LOSS_BLOCKS * 2 * sizeof(float); }
+size_t mvae_bce_kl_loss_workspace(int64_t, int64_t) { return (size_t)LOSS_BLOCKS * 2 * sizeof(float) + 16; }
 int mvae_bce_kl_loss_fwd(int64_t n, const float* recon, const float* target, int64_t m, const float* mu, const float* logvar,
                          float max_len, float* loss_out, void* ws, size_t ws_bytes, void* stream) {
   if (!recon || !target || !mu || !logvar || !loss_out || n < 1 || m < 1) return MVAE_ERR_INVALID;
-  if (!ws || ws_bytes < mvae_bce_kl_loss_workspace(n, m)) return MVAE_ERR_WORKSPACE;
+  if (!ws || ws_bytes < mvae_bce_kl_loss_workspace(n, m) || (reinterpret_cast<uintptr_t>(ws) & 3)) return MVAE_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bce_kl_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, (long)n, recon, target, (long)m, mu, logvar, (float*)ws);
-  hipLaunchKernelGGL(bce_kl_final_kernel, dim3(1), dim3(64), 0, st, LOSS_BLOCKS, (const float*)ws, (long)n, (long)m, max_len, loss_out);
+  // enough blocks to keep the HBM queues full (>= 2 per CU), few enough that the tickets -- atomics on ONE address, which the memory side
+  // serialises at ~10 ns each -- and the finishing block's pass over the partials stay short: 8 16-byte pieces per thread, at most 1024 blocks
+  long want = (n / 4 + 256 * 8 - 1) / (256 * 8);
+  const int blocks = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  float* partial = reinterpret_cast<float*>(ws);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(partial + 2 * LOSS_BLOCKS);
+  hipLaunchKernelGGL(bce_kl_fused_kernel, dim3(blocks), dim3(256), 0, st, (long)n, recon, target, (long)m, mu, logvar, max_len, partial, ticket, loss_out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

@@ -92,6 +92,34 @@ class DeviceDataset:
             yield idx, ohe
 
 
+def synthetic_smiles(n, seed=0, lo=20, hi=60, structured=True):
+    """A stand-in corpus over the ZINC alphabet (no data set ships with the reference: .MISSING_LARGE_BLOBS).  structured: every string is
+    a short random motif repeated to its length, so that a model can learn something in a few hundred steps (tests / examples);
+    otherwise i.i.d. characters."""
+    rs = np.random.RandomState(seed)
+    alphabet = list("CNOSFcnos()=#123[]@H+-lBr")
+    out = []
+    for _ in range(n):
+        ln = int(rs.randint(lo, hi))
+        if structured:
+            m = rs.choice(alphabet, size=int(rs.randint(3, 8)))
+            out.append("".join(np.resize(m, ln)))
+        else:
+            out.append("".join(rs.choice(alphabet, size=ln)))
+    return out
+
+
+def indices_to_smiles(idx, charset):
+    """Rows of class indices -> strings, right-stripped of the padding character (train_sample.py:36: "".join(charset[i]).rstrip()).
+    `charset`: id -> char (dict or list), the ``charset`` entry of the reference's checkpoints (train.py:174)."""
+    arr = np.asarray(idx.detach().cpu() if hasattr(idx, "detach") else idx)
+    if isinstance(charset, dict):
+        table = np.array([charset[i] for i in range(len(charset))])
+    else:
+        table = np.array(list(charset))
+    return ["".join(table[row]).rstrip() for row in arr]
+
+
 def load_smiles(path, column=0):
     """.smi / headerless CSV: one molecule per line, SMILES in `column` (train.py:41 pd.read_csv(..., header=None))."""
     out = []

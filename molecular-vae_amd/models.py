@@ -148,6 +148,49 @@ class _Workspace:
         return b
 
 
+class _SavedState:
+    """Mixin: where a module's forward keeps what its backward reads.  By default ONE workspace (`_ws`, which also holds the packed weight
+    shadows): a forward overwrites the previous forward's saved state, so `fwd, fwd, bwd(first)` raises -- at that backward, because only
+    then is it known that the first forward is still wanted (train.py:120-153 runs forward after forward with gradients enabled and never
+    calls backward).  `saved_state_depth = n` keeps a ring of n workspaces (n x the activation memory): up to n forward passes of the SAME
+    module may be outstanding, backpropagated in any order (micro-batches interleaved by hand, two losses from two forwards)."""
+
+    def _init_saved_state(self):
+        self._ws = _Workspace()
+        self.__dict__["_ring"] = [self._ws]
+        self.__dict__["_turn"] = 0
+
+    @property
+    def saved_state_depth(self):
+        return len(self.__dict__["_ring"])
+
+    @saved_state_depth.setter
+    def saved_state_depth(self, n):
+        ring = self.__dict__["_ring"]
+        if n < 1:
+            raise ValueError("saved_state_depth must be >= 1")
+        while len(ring) < n:
+            ring.append(_Workspace())
+        del ring[n:]
+        self.__dict__["_turn"] = 0
+
+    def _next_saved_ws(self):
+        """(slot, workspace) for the forward that is starting; bumps that slot's generation."""
+        ring = self.__dict__["_ring"]
+        self.__dict__["_turn"] = slot = (self.__dict__["_turn"] + 1) % len(ring)
+        ring[slot].generation += 1
+        return slot, ring[slot]
+
+    def _saved_ws(self, slot, gen, what):
+        ring = self.__dict__["_ring"]
+        if slot >= len(ring) or ring[slot].generation != gen:
+            raise L.MvaeError(f"{what}: the state this forward saved was overwritten by a later forward of the same module (or it ran under "
+                              f"no_grad); run backward before the next forward, or set `module.saved_state_depth` to the number of forward "
+                              f"passes kept outstanding (now {len(ring)})")
+        return ring[slot]
+
+
+
 _LDPAD = 64   # elements added to power-of-two leading dimensions of the big recurrent operands
 def _dyk(n_out):
     """K extent of the output-gradient product dy = dl . W_out (see MolDecoder): the class / vocabulary count rounded up to whole pairs of
@@ -253,7 +296,7 @@ class Lambda(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------- encoder
-class MolEncoder(nn.Module):
+class MolEncoder(nn.Module, _SavedState):
     """models.py:109-135: Embedding -> LSTM(30->72, 3 layers) -> 3 x (Conv1d k=18 + SELU) -> Linear+SELU -> Lambda."""
 
     def __init__(self, i=120, o=292, c=35, word_embedding_size=30, h_size=72, num_lstm=3):
@@ -266,7 +309,8 @@ class MolEncoder(nn.Module):
         self.conv_3 = ConvSELU(64, 64, kernel_size=18)
         self.dense_1 = nn.Sequential(LinearWeights((h_size - (18 * 3) + 3) * 64, 512), SELU(inplace=True))
         self.lmbd = Lambda(512, o)
-        self._ws = _Workspace()
+        self._init_saved_state()
+        self.__dict__["_fork"] = ops.ForkState()   # side-stream work of the decoder paired with us (MolecularVAE shares one object between the two)
         self.fast_grad_gemms = False      # set by MolecularVAE in bf16 mode (conv input-gradient GEMMs as 3 x bf16 products)
         self._pack_key = None
         self._packed = {}
@@ -352,8 +396,7 @@ class _EncoderFn(torch.autograd.Function):
         H, NL, Cv = g.hidden_size, g.num_layers, mod.embedding.num_embeddings
         o = mod.lmbd.z_mean.out_features
         P = mod._pack(dev)
-        ws = mod._ws
-        ws.generation += 1
+        slot, ws = mod._next_saved_ws()
         f32 = torch.float32
         G4 = 4 * H
         # K1: embedding folded into the layer-0 input projection: table = E . W_ih0^T + (b_ih0 + b_hh0)
@@ -399,15 +442,14 @@ class _EncoderFn(torch.autograd.Function):
         ops.gemm_nt(d, P["Wml"], mulv, B, 2 * o, 512, bias=P["bml"])
         z = torch.empty(B, o, dtype=f32, device=dev); mu = torch.empty_like(z); logv = torch.empty_like(z)
         ops.lambda_fwd(mulv, eps, z, mu, logv, B, o)
-        ctx.mod, ctx.gen, ctx.idx, ctx.eps = mod, ws.generation, idx, eps
+        ctx.mod, ctx.slot, ctx.gen, ctx.idx, ctx.eps = mod, slot, ws.generation, idx, eps
         return z, mu, logv
 
     @staticmethod
     def backward(ctx, dz, dmu, dlogv):
         mod, idx, eps = ctx.mod, ctx.idx, ctx.eps
-        ws = mod._ws
-        if ws.generation != ctx.gen:
-            raise L.MvaeError("MolEncoder workspace was overwritten by a later forward; run backward before the next forward")
+        ws = mod._saved_ws(ctx.slot, ctx.gen, "MolEncoder")
+        fork = mod.__dict__["_fork"]
         dev = idx.device
         f32 = torch.float32
         B, Lq = idx.shape
@@ -448,7 +490,7 @@ class _EncoderFn(torch.autograd.Function):
         ops.colsum(dd, B, 512, grads["dense_1.0.bias"])
         dflat = W("dflat", (B, F))
         ops.gemm_nt(dd, P["W1T"], dflat, B, F, 512)
-        ops.run_deferred(0)       # the decoder's upper-layer weight-gradient GEMMs: from here on our own launches are chip-filling too
+        fork.run_deferred(0)      # the decoder's upper-layer weight-gradient GEMMs: from here on our own launches are chip-filling too
         # K3 backward
         c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
         k = c1.kernel_size
@@ -477,7 +519,7 @@ class _EncoderFn(torch.autograd.Function):
         gates = [W(f"gates{l}", (Lq, B, G4)) for l in range(NL)]
         dG = [W(f"dG{l}", (Lq, B, G4)) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
-        ops.run_deferred(1)       # the decoder's remaining weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
+        fork.run_deferred(1)      # the decoder's remaining weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
         ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, Hp, cs, gates,
                     dG, dstate, tag="enc_lstm_bwd")
         _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp)
@@ -489,12 +531,12 @@ class _EncoderFn(torch.autograd.Function):
         dtblT = W("dtblT", (G4, Cp))
         ops.cast_transpose(dtbl, Cv, G4, dstT=dtblT)
         ops.gemm_nt(dtblT, P["ET"], grads["gru.weight_ih_l0"], G4, E, Cp)
-        ops.join_pending()        # the decoder's weight-gradient GEMMs that ran on the side stream under this backward
+        fork.join()               # the decoder's weight-gradient GEMMs that ran on the side stream under this backward
         return (None, None, None) + tuple(grads[n] for n in names)
 
 
 # ----------------------------------------------------------------------------------------------- decoder
-class MolDecoder(nn.Module):
+class MolDecoder(nn.Module, _SavedState):
     """models.py:148-165: Linear+SELU -> repeat L -> LSTM(292->1024, 4 layers) -> Linear(1024,C) -> softmax over C."""
 
     def __init__(self, i=292, o=120, c=35, num_gru=4, h_size=1024, dtype=torch.bfloat16):
@@ -504,7 +546,7 @@ class MolDecoder(nn.Module):
         self.gru = RNNWeights("LSTM", i, h_size, num_gru)                           # models.py:156: named gru, is an LSTM
         self.decoded_mean = TimeDistributed(nn.Sequential(LinearWeights(h_size, c), Softmax()))
         self.compute_dtype = dtype
-        self._ws = _Workspace()
+        self._init_saved_state()
         self._pack_key = None
         self._packed = {}
         self.__dict__["_peer"] = None          # weakref to the encoder whose backward runs after ours (set by MolecularVAE)
@@ -575,8 +617,7 @@ class _DecoderFn(torch.autograd.Function):
         Cv = om.out_features
         G4, TB = 4 * H, Lq * B
         P = mod._pack(dev)
-        ws = mod._ws
-        ws.generation += 1
+        slot, ws = mod._next_saved_ws()
         f32 = torch.float32
         li_mod = mod.latent_input[0]
         # K6: latent projection + SELU; layer-0 input is time-invariant -> its gate pre-activation is computed ONCE
@@ -598,7 +639,7 @@ class _DecoderFn(torch.autograd.Function):
         recon = torch.empty(B, Lq, Cv, dtype=f32, device=dev)
         with ops._Timed("hbm_softmax_fwd"):
             ops.softmax_tb_fwd(logits, Cv, recon, B, Lq, Cv)
-        ctx.mod, ctx.gen, ctx.z = mod, (-1 if infer else ws.generation), z     # a forward-only pass saved nothing: backward refuses
+        ctx.mod, ctx.slot, ctx.gen, ctx.z = mod, slot, (-1 if infer else ws.generation), z     # a forward-only pass saved nothing: backward refuses
         ctx.from_peer = bool(mod.__dict__.get("_z_from_peer", False))
         ctx.save_for_backward(recon)
         return recon
@@ -607,9 +648,7 @@ class _DecoderFn(torch.autograd.Function):
     def backward(ctx, drecon):
         mod, z = ctx.mod, ctx.z
         (recon,) = ctx.saved_tensors
-        ws = mod._ws
-        if ws.generation != ctx.gen:
-            raise L.MvaeError("MolDecoder workspace was overwritten by a later forward; run backward before the next forward")
+        ws = mod._saved_ws(ctx.slot, ctx.gen, "MolDecoder")
         dev = z.device
         f32 = torch.float32
         g, dt = mod.gru, mod.compute_dtype
@@ -691,8 +730,8 @@ class _DecoderFn(torch.autograd.Function):
 
         # Fork: the weight-gradient GEMMs are throughput-bound and independent of dz, while the encoder's backward that follows is a
         # latency-bound chain of small launches -> run them concurrently.  Only when our MolecularVAE peer will join the side stream
-        # (its backward ends with ops.join_pending) and no gradient accumulation is pending (p.grad is assigned, never added to).
-        # The two lowest layers' GEMMs are parked (ops.DEFERRED): the peer releases them right before its row-resident LSTM backward,
+        # (its backward ends with ForkState.join) and no gradient accumulation is pending (p.grad is assigned, never added to).
+        # The two lowest layers' GEMMs are parked (ops.ForkState): the peer releases them right before its row-resident LSTM backward,
         # whose 128 workgroups leave half the CUs idle -- the GEMMs fill them instead of running alone later.
         peer = mod.__dict__["_peer"]() if mod.__dict__["_peer"] is not None else None
         fork = bool(mod.overlap_weight_grads and peer is not None and ctx.from_peer and ctx.needs_input_grad[1] and
@@ -700,8 +739,9 @@ class _DecoderFn(torch.autograd.Function):
         if fork:
             side = mod._side_stream(dev)
             gflat.record_stream(side)
-            ops.DEFERRED.append((side, lambda: weight_grads(0), 0))      # released by the peer after its head section (see ops.DEFERRED)
-            ops.DEFERRED.append((side, lambda: weight_grads(1), 1))      # released next to the peer's row-resident LSTM backward
+            fstate = peer.__dict__["_fork"]                               # the model's own fork state (ops.ForkState), kept by the peer
+            fstate.park(side, lambda: weight_grads(0), 0)                 # released by the peer after its head section
+            fstate.park(side, lambda: weight_grads(1), 1)                 # released next to the peer's row-resident LSTM backward
         else:
             weight_grads(None)
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
@@ -733,7 +773,7 @@ class MolecularVAE(nn.Module):
         super().__init__()
         self.encoder = MolEncoder(i=i, o=o, c=c)
         self.decoder = MolDecoder(i=o, o=i, c=c, dtype=dtype)
-        self.decoder.__dict__["_peer"] = weakref.ref(self.encoder)
+        self.decoder.__dict__["_peer"] = weakref.ref(self.encoder)      # the fork state the decoder parks work in is the encoder's (_fork)
         self.prepack_decoder = True       # refresh the decoder's weight shadows on the side stream beside the encoder's forward
         # bf16 mode: the encoder's conv INPUT-gradient GEMMs multiply as 3 x bf16 products (~16 mantissa bits, 3/16 of the f32 MFMA cycles);
         # the forward pass of the encoder (what mu / logvar / the ELBO are made of) is exact fp32 in both modes

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .models import LinearWeights, Conv1dWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _dyk
+from .models import LinearWeights, Conv1dWeights, RNNWeights, _Workspace, _SavedState, _params_key, _pad, _require_cuda, _LDPAD, _dyk
 from .mosesvae import _kmajor_gemm
 
 SEQ, VOCAB, HID, HP, NLAY = 120, 35, 501, 512, 3
@@ -37,7 +37,7 @@ def _slots4p(w3, H, Hp, Kp, order):
     return out
 
 
-class VAE(nn.Module):
+class VAE(nn.Module, _SavedState):
     def __init__(self, dtype=torch.bfloat16):
         super().__init__()
         self.conv1d1 = Conv1dWeights(SEQ, 9, 9)          # models2d.py:12-21, same construction order (same RNG stream under manual_seed)
@@ -50,7 +50,7 @@ class VAE(nn.Module):
         self.gru = RNNWeights("GRU", 2, HID, NLAY)
         self.fc3 = LinearWeights(HID, VOCAB)
         self.compute_dtype = dtype
-        self._ws = _Workspace()
+        self._init_saved_state()
         self._pack_key, self._packed = None, {}
 
     # -- the reference's method surface
@@ -160,8 +160,7 @@ def _decode_only(mod, z):
     dev = z.device
     _require_cuda(dev, "models2d.VAE.decode")
     P = mod._pack(dev)
-    ws = mod._ws
-    ws.generation += 1
+    _, ws = mod._next_saved_ws()
     B = z.shape[0]
     W = lambda name, shape, d=torch.float32: ws.get(name, shape, d, dev)
     zp = W("zp", (B, 4)); zp[:, :2].copy_(z)
@@ -174,8 +173,8 @@ class _Models2dFn(torch.autograd.Function):
         dev = x.device
         _require_cuda(dev, "models2d.VAE")
         P = mod._pack(dev)
-        ws, f32 = mod._ws, torch.float32
-        ws.generation += 1
+        f32 = torch.float32
+        slot, ws = mod._next_saved_ws()
         B = x.shape[0]
         W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
         # ---- encoder (models2d.py:23-29): the one-hot block, channels-last [b][v][t]
@@ -193,7 +192,7 @@ class _Models2dFn(torch.autograd.Function):
         zp = W("zp", (B, 4)); zp[:, :2].copy_(z)
         # ---- decoder (:40-47)
         recon = _decoder_forward(mod, P, W, zp, B, dev, infer)
-        ctx.mod, ctx.gen, ctx.eps, ctx.B = mod, (-1 if infer else ws.generation), eps, B
+        ctx.mod, ctx.slot, ctx.gen, ctx.eps, ctx.B = mod, slot, (-1 if infer else ws.generation), eps, B
         ctx.save_for_backward(recon)
         return recon, mu, logvar
 
@@ -201,10 +200,7 @@ class _Models2dFn(torch.autograd.Function):
     def backward(ctx, drecon, dmu_ext, dlv_ext):
         mod, eps, B = ctx.mod, ctx.eps, ctx.B
         (recon,) = ctx.saved_tensors
-        ws = mod._ws
-        if ws.generation != ctx.gen:
-            raise L.MvaeError("models2d.VAE workspace was overwritten by a later forward (or the forward ran under no_grad); run backward "
-                              "right after its own forward")
+        ws = mod._saved_ws(ctx.slot, ctx.gen, "models2d.VAE")
         dev = recon.device
         P, dt, f32 = mod._packed, mod.compute_dtype, torch.float32
         W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)

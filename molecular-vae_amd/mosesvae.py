@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _params_key, _pad, _require_cuda, _LDPAD, _dyk
+from .models import LinearWeights, EmbeddingWeights, RNNWeights, _Workspace, _SavedState, _params_key, _pad, _require_cuda, _LDPAD, _dyk
 from .vocab import PaddedBatch, pad_batch
 
 
@@ -40,7 +40,7 @@ def _slots4(w3, H, order):
     return out
 
 
-class VAE(nn.Module):
+class VAE(nn.Module, _SavedState):
     def __init__(self, vocab, dtype=torch.bfloat16):
         super().__init__()
         q_d_h, q_n_layers, d_n_layers, d_dropout, d_z, d_d_h = 256, 1, 3, 0.2, 160, 512     # mosesvae.py:31-40
@@ -69,7 +69,7 @@ class VAE(nn.Module):
         self.dp_group = None                 # process group of that reduction (None: the default group); moses_train_step sets it from the optimiser's GradSync
         self.last_drop_seed = None           # seed of the most recent train-mode forward (None: eval / injected mask)
         self.compute_dtype = dtype
-        self._ws = _Workspace()
+        self._init_saved_state()
         self._pack_key, self._packed = None, {}
 
     @property
@@ -255,8 +255,8 @@ class _MosesFn(torch.autograd.Function):
         dev = x_pad.device
         _require_cuda(dev, "mosesvae.VAE")
         P = mod._pack(dev)
-        ws, dt, f32 = mod._ws, mod.compute_dtype, torch.float32
-        ws.generation += 1
+        dt, f32 = mod.compute_dtype, torch.float32
+        slot, ws = mod._next_saved_ws()
         B, T = x_pad.shape
         V, dz = mod.x_emb.num_embeddings, mod.d_z
         Vp = _pad(V, 4)
@@ -308,7 +308,7 @@ class _MosesFn(torch.autograd.Function):
         ops.gemm_nt(hsx_d[-1][1:].reshape(TB, ldh_d), P["Wfc"], y_tb, TB, V, Hd, bias=mod.decoder_fc.bias)
         y = torch.empty(B, T, V, device=dev); ops.permute102(y_tb, y, T, B, V)
         loss2 = W("loss2", (2,)); ops.ce_loss_fwd(y_tb, V, x_pad, mod.pad, loss2, B, T, V)
-        ctx.mod, ctx.gen, ctx.x_pad, ctx.lengths, ctx.eps, ctx.drop = mod, ws.generation, x_pad, lengths, eps, drop
+        ctx.mod, ctx.slot, ctx.gen, ctx.x_pad, ctx.lengths, ctx.eps, ctx.drop = mod, slot, ws.generation, x_pad, lengths, eps, drop
         ctx.set_materialize_grads(False)
         ntok = loss2[1].clone()
         ctx.mark_non_differentiable(ntok)
@@ -317,9 +317,7 @@ class _MosesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dkl, drecon, dz_ext, dlv_ext, dy_ext, _dntok=None):
         mod, x_pad, lengths, eps, drop = ctx.mod, ctx.x_pad, ctx.lengths, ctx.eps, ctx.drop
-        ws = mod._ws
-        if ws.generation != ctx.gen:
-            raise L.MvaeError("mosesvae.VAE workspace was overwritten by a later forward; run backward before the next forward")
+        ws = mod._saved_ws(ctx.slot, ctx.gen, "mosesvae.VAE")
         dev = x_pad.device
         P, dt, f32 = mod._packed, mod.compute_dtype, torch.float32
         B, T = x_pad.shape

@@ -3,6 +3,7 @@
 Every function launches HIP kernels on torch's current stream and raises on any non-zero status.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -36,39 +37,50 @@ class _Timed:
         return False
 
 
-# events of work forked onto a side stream that nobody has joined yet (joined by the encoder's backward / FusedAdam.step)
-PENDING = []
+class ForkState:
+    """Side-stream bookkeeping of ONE model (a MolDecoder and the MolEncoder whose backward follows it share one): `pending` = events of work
+    forked onto a side stream that nobody has joined yet (joined by the encoder's backward / FusedAdam.step); `deferred` = (side stream,
+    callable, stage): throughput-bound work its owner parked so that the peer can release it at a chosen point of ITS launch sequence.
+    The decoder parks its weight-gradient GEMMs in two stages: stage 0 is released by the encoder's backward once its head section (a dozen
+    tiny launches that would otherwise each wait for a chip-filling GEMM workgroup to retire) is enqueued, stage 1 right before its
+    row-resident LSTM backward, whose 128 workgroups leave half the CUs idle.  Whoever reaches run_deferred() / join() first runs it.
+    Per model, not per process: two models stepping in one process never see each other's parked work."""
+    _all = weakref.WeakSet()
 
+    def __init__(self):
+        self.pending, self.deferred = [], []
+        ForkState._all.add(self)
 
-# (side stream, callable, stage): throughput-bound work its owner parked so that a peer can release it at a chosen point of ITS launch
-# sequence.  The decoder parks its weight-gradient GEMMs in two stages: stage 0 is released by the encoder's backward once its head section
-# (a dozen tiny launches that would otherwise each wait for a chip-filling GEMM workgroup to retire) is enqueued, stage 1 right before its
-# row-resident LSTM backward, whose 128 workgroups leave half the CUs idle.  Whoever reaches run_deferred() / join_pending() first runs it.
-DEFERRED = []
+    def park(self, side, fn, stage):
+        self.deferred.append((side, fn, stage))
 
+    def run_deferred(self, stage=None):
+        """Launch the parked work of stages <= `stage` (None: all) on its side stream, ordered after everything issued so far on the current stream."""
+        keep = []
+        while self.deferred:
+            side, fn, st = self.deferred.pop(0)
+            if stage is not None and st > stage:
+                keep.append((side, fn, st))
+                continue
+            ev = torch.cuda.Event(); ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn()
+                e2 = torch.cuda.Event(); e2.record()
+            self.pending.append(e2)
+        self.deferred.extend(keep)
 
-def run_deferred(stage=None):
-    """Launch the parked work of stages <= `stage` (None: all) on its side stream, ordered after everything issued so far on the current stream."""
-    keep = []
-    while DEFERRED:
-        side, fn, st = DEFERRED.pop(0)
-        if stage is not None and st > stage:
-            keep.append((side, fn, st))
-            continue
-        ev = torch.cuda.Event(); ev.record()
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            fn()
-            e2 = torch.cuda.Event(); e2.record()
-        PENDING.append(e2)
-    DEFERRED.extend(keep)
+    def join(self):
+        """Make the current stream wait for every forked piece of work of this model (weight-gradient GEMMs on the side stream)."""
+        self.run_deferred()
+        while self.pending:
+            torch.cuda.current_stream().wait_event(self.pending.pop())
 
 
 def join_pending():
-    """Make the current stream wait for every forked piece of work (weight-gradient GEMMs on the side stream)."""
-    run_deferred()
-    while PENDING:
-        torch.cuda.current_stream().wait_event(PENDING.pop())
+    """Join the forked work of EVERY live model (FusedAdam.step: an optimiser may hold the parameters of several)."""
+    for fs in list(ForkState._all):
+        fs.join()
 
 
 def release_caches():
@@ -83,11 +95,16 @@ class Scratch:
     _bufs = {}
 
     @classmethod
-    def get(cls, nbytes, device, tag=""):
+    def get(cls, nbytes, device, tag="", zeroed=False):
+        """zeroed: the buffer is allocated zero and only ever handed to call sites of this `tag` (kernels that keep a self-resetting
+        counter in it, e.g. the loss's ticket)."""
         key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0, tag)
         b = cls._bufs.get(key)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            if zeroed:
+                b = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+            else:
+                b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             cls._bufs[key] = b
         return b
 
@@ -311,7 +328,7 @@ def softmax_tb_bwd(recon, drecon, dl, dlT, B, Lq, C_):
 def bce_kl_loss_fwd(recon, target, mu, logvar, max_len, out3):
     lib = L.load()
     need = lib.mvae_bce_kl_loss_workspace(recon.numel(), mu.numel())
-    ws = Scratch.get(need, recon.device)
+    ws = Scratch.get(need, recon.device, tag="bce_kl_ticket", zeroed=True)     # the kernel's ticket counter lives in its last 16 bytes
     check(lib.mvae_bce_kl_loss_fwd(recon.numel(), ptr(recon), ptr(target), mu.numel(), ptr(mu), ptr(logvar), float(max_len),
                                    ptr(out3), ptr(ws), need, stream_ptr()), "mvae_bce_kl_loss_fwd")
 

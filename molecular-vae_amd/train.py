@@ -330,6 +330,27 @@ def evaluate(model, loss_function, batches):
     return float(total) / n, float(right) / n_seq
 
 
+@torch.no_grad()
+def generate_from_latent(model, charset, n=None, z=None, batch_size=2000, generator=None):
+    """``train_sample.py:29-45`` without the rdkit filter: decode latent vectors with ``model.decoder`` (forward-only pass: nothing is saved
+    for backward), arg-max over the class axis (``torch.max(recon_batch, dim=2)``), map ids through ``charset`` and right-strip the padding.
+    ``z`` [N, latent] or ``n`` draws ``torch.rand`` latents as the reference does (uniform on [0, 1)).  Returns (list of strings, z)."""
+    from .data import indices_to_smiles
+    dec = model.decoder if hasattr(model, "decoder") else model
+    dev = next(dec.parameters()).device
+    o = dec.latent_input[0].in_features
+    if z is None:
+        if n is None:
+            raise ValueError("give n or z")
+        z = torch.rand(n, o, device=dev, generator=generator)
+    z = z.to(dev).float()
+    out = []
+    for lo in range(0, z.shape[0], batch_size):
+        recon = dec(z[lo:lo + batch_size])
+        out.extend(indices_to_smiles(recon.argmax(dim=2), charset))
+    return out, z
+
+
 def strip_module_prefix(state_dict):
     """Keys saved from ``nn.DataParallel(model)`` (train_distributed.py:72,145-151) carry a ``module.`` prefix; the strip of
     mosesanalyize.py:171-173, applied only to keys that have it."""

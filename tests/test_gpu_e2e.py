@@ -1,0 +1,166 @@
+"""End-to-end GPU tests (-m gpu): the re-hosted trainers of the reference (train.py:156-177, moses_train_distrib.py:334-356) run as child
+processes on a synthetic corpus -- loss goes down, the checkpoint the run wrote reloads into a fresh model and reproduces the validation
+loss the run printed; the MolDecoder-from-latent generator (train_sample.py:29-45); two models / several outstanding forwards in one process."""
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import molecular_vae_amd as mv
+    from molecular_vae_amd import data as D, ops
+    dev = torch.device("cuda", 0)
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, f"{' '.join(cmd)}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-3000:]}"
+    return r
+
+
+def test_train_zinc_example_trains_checkpoints_and_reloads(tmp_path):
+    out = str(tmp_path)
+    rep = os.path.join(out, "report.json")
+    _run([sys.executable, os.path.join(ROOT, "examples", "train_zinc.py"), "-b", "128", "--epochs", "3", "--n_synth", "3072", "--out_dir", out,
+          "--report", rep])
+    r = json.load(open(rep))
+    ep = r["epochs"]
+    assert len(ep) == 3 and all(np.isfinite(e["mean_batch_loss"]) and np.isfinite(e["val_loss"]) for e in ep)
+    assert ep[-1]["mean_batch_loss"] < 0.9 * ep[0]["first_batch_loss"], ep              # it learns (motif corpus)
+    assert ep[-1]["val_loss"] < ep[0]["val_loss"]
+    assert ep[-1]["molecules_per_s_through_pipeline"] > 0
+    # the checkpoint of train.py:170-177 reloads into a FRESH model and reproduces the validation loss of the last epoch
+    ck = torch.load(r["checkpoint"], map_location="cpu", weights_only=False)
+    assert set(ck) >= {"model_state_dict", "optimizer_state_dict", "epoch", "charset", "max_len", "lr", "latent_size"} and ck["epoch"] == 3
+    smiles = D.synthetic_smiles(3072, seed=0)
+    vocab = D.build_vocab(smiles, 120)
+    assert {i: c for c, i in vocab.items()} == ck["charset"]
+    enc = D.encode_smiles(smiles, vocab, 120)
+    msk = np.random.RandomState(1).rand(len(enc)) < 0.8
+    test_ds = D.DeviceDataset(enc[~msk], len(vocab), dev)
+    model = mv.MolecularVAE(i=ck["max_len"], c=len(ck["charset"]), o=ck["latent_size"]).to(dev)
+    opt = mv.FusedAdam(model.parameters(), lr=1.0, max_grad_norm=3.0)
+    mv.load_checkpoint(r["checkpoint"], model, opt)
+    assert abs(opt.param_groups[0]["lr"] - ck["lr"]) < 1e-12
+    val, acc = mv.evaluate(model, mv.make_loss_function(120), test_ds.batches(128, shuffle=False, drop_last=False))
+    # (the reparameterisation noise of models.py:92 is drawn afresh in every forward, here and in the child run: 1e-2-scaled, so the two
+    # evaluations agree to ~1e-5, not to the bit)
+    assert abs(val - ep[-1]["val_loss"]) < 1e-3 * abs(val) and abs(acc - ep[-1]["val_acc"]) < 0.02
+    # generation from latents (train_sample.py:29-45): decoder-only forward pass, arg-max, charset, rstrip
+    g = torch.Generator(device="cuda").manual_seed(3)
+    strings, z = mv.generate_from_latent(model, ck["charset"], n=96, batch_size=40, generator=g)
+    assert len(strings) == 96 and z.shape == (96, 292) and float(z.min()) >= 0 and float(z.max()) < 1
+    with torch.no_grad():
+        want = D.indices_to_smiles(model.decoder(z).argmax(dim=2), ck["charset"])
+    assert strings == want and all(set(s) <= set(vocab) and not s.endswith(" ") and len(s) <= 120 for s in strings)
+    again, _ = mv.generate_from_latent(model, ck["charset"], z=z)
+    assert again == strings
+
+
+def test_train_moses_example_trains_and_its_artefacts_reload(tmp_path):
+    out = str(tmp_path)
+    rep = os.path.join(out, "report.json")
+    _run([sys.executable, os.path.join(ROOT, "examples", "train_moses.py"), "-b", "128", "--epochs", "3", "--n_synth", "2048", "--n_samples", "16",
+          "--out_dir", out, "--report", rep])
+    r = json.load(open(rep))
+    ep = r["epochs"]
+    assert len(ep) == 3 and ep[-1]["recon_loss"] < ep[0]["recon_loss"] and all(np.isfinite(e["loss"]) for e in ep)
+    assert [e["kl_weight"] for e in ep] == [0.0, 1 / 3, 2 / 3]                            # KLAnnealer(3): moses_train_distrib.py:47-58
+    assert len(r["samples"]) == 16 and all(isinstance(s, str) for s in r["samples"])
+    from molecular_vae_amd import mosesvae as MV
+    vocab = pickle.load(open(os.path.join(out, "vocab.pkl"), "rb"))
+    model = MV.VAE(vocab).to(dev)
+    model.load_state_dict(torch.load(os.path.join(out, "trained_save.pt"), map_location="cpu"))
+    model.eval()
+    seqs = sorted([model.string2tensor(s) for s in ["CCO", "c1ccccc1", "CC(=O)N"]], key=len, reverse=True)
+    kl, rec, *_ = model(seqs)
+    assert np.isfinite(float(kl)) and np.isfinite(float(rec))
+
+
+def test_two_models_step_alternately_in_one_process():
+    """Two MolecularVAE instances with their own optimisers, stepped alternately (and once through ONE backward of a summed loss): each
+    follows exactly the trajectory it follows alone -- the side-stream fork state (ops.ForkState) is per model."""
+    L_, C_, B = 120, 35, 32
+    gen = torch.Generator().manual_seed(11)
+    batches = [(torch.randint(0, C_, (B, L_), generator=gen).to(dev), (1e-2 * torch.randn(B, 292, generator=gen)).to(dev)) for _ in range(4)]
+    loss_fn = mv.make_loss_function(L_)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = mv.MolecularVAE().to(dev)
+        return m, mv.FusedAdam(m.parameters(), lr=8e-4, max_grad_norm=3.0)
+
+    def solo(seed):
+        m, o = make(seed)
+        out = [float(mv.train_step(m, o, loss_fn, ix, torch.nn.functional.one_hot(ix, C_).float(), eps=ep)) for ix, ep in batches]
+        return out, float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+
+    ref_a, ref_b = solo(1), solo(2)
+    (ma, oa), (mb, ob) = make(1), make(2)
+    la, lb = [], []
+    for k, (ix, ep) in enumerate(batches):
+        oh = torch.nn.functional.one_hot(ix, C_).float()
+        if k == 2:                                               # both models in ONE autograd graph / one backward call
+            oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+            ra, mua, lva = ma(ix, eps=ep); rb, mub, lvb = mb(ix, eps=ep)
+            l1, l2 = loss_fn(ra, oh, mua, lva), loss_fn(rb, oh, mub, lvb)
+            (l1 + l2).backward()
+            oa.step(); ob.step()
+            la.append(float(l1)); lb.append(float(l2))
+        else:
+            la.append(float(mv.train_step(ma, oa, loss_fn, ix, oh, eps=ep)))
+            lb.append(float(mv.train_step(mb, ob, loss_fn, ix, oh, eps=ep)))
+    pa = float(sum(p.detach().double().abs().sum() for p in ma.parameters()))
+    pb = float(sum(p.detach().double().abs().sum() for p in mb.parameters()))
+    assert la == ref_a[0] and lb == ref_b[0] and pa == ref_a[1] and pb == ref_b[1]
+    del ma, mb, oa, ob
+    ops.release_caches(); torch.cuda.empty_cache()
+
+
+def test_two_outstanding_forwards_of_one_module_with_a_saved_state_ring():
+    """saved_state_depth = 2: forward(x1), forward(x2), then backward of both (in either order) gives the gradients of two separate
+    forward/backward rounds added up; with the default depth the first backward raises a clear error naming the knob."""
+    from molecular_vae_amd import _lib as LL
+    torch.manual_seed(5)
+    model = mv.MolecularVAE(dtype=torch.float32).to(dev)
+    gen = torch.Generator().manual_seed(12)
+    xs = [torch.randint(0, 35, (8, 120), generator=gen).to(dev) for _ in range(2)]
+    es = [(1e-2 * torch.randn(8, 292, generator=gen)).to(dev) for _ in range(2)]
+    loss_fn = mv.make_loss_function(120)
+
+    def loss_of(i):
+        r, mu, lv = model(xs[i], eps=es[i])
+        return loss_fn(r, torch.nn.functional.one_hot(xs[i], 35).float(), mu, lv)
+
+    model.zero_grad(set_to_none=True)
+    for i in range(2):
+        loss_of(i).backward()                                    # sequential rounds: autograd accumulates
+    want = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    l0 = loss_of(0); l1 = loss_of(1)
+    with pytest.raises(LL.MvaeError, match="saved_state_depth"):
+        l0.backward()
+    for m in (model.encoder, model.decoder):
+        m.saved_state_depth = 2
+    for order in ((0, 1), (1, 0)):
+        model.zero_grad(set_to_none=True)
+        ls = [loss_of(0), loss_of(1)]
+        for i in order:
+            ls[i].backward()
+        for k, p in model.named_parameters():
+            assert torch.allclose(p.grad, want[k], rtol=1e-5, atol=1e-7), (order, k)
+    del model
+    ops.release_caches(); torch.cuda.empty_cache()

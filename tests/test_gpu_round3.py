@@ -290,3 +290,60 @@ def test_bf16_storage_tracks_f32_over_200_optimiser_steps():
     assert np.abs(a - b).max() / a.min() < 1.5e-2 and abs(a[-1] - b[-1]) < 1e-2 * a[-1], (a, b)
     del m32, mbf, o32, obf
     ops.release_caches(); torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------- HBM-bound kernels of the head (round 3)
+@pytest.mark.parametrize("shape", [(1024, 120, 35), (37, 13, 35), (20, 40, 64), (5, 7, 3), (48, 16, 128), (16, 16, 41), (130, 9, 12), (24, 10, 48), (9, 6, 24), (33, 7, 16), (2048, 64, 64)])
+def test_tiled_softmax_head_forward_and_backward(shape, monkeypatch):
+    """The LDS-tiled softmax head (one row per thread, both layouts moved as flat 16-byte streams): whole tiles, ragged tiles in both
+    directions, class counts on either side of the 16 x 16 / 8 x 16 tile switch, odd and even C, unaligned runs (scalar fallback) --
+    forward against a float64 softmax, backward (bf16 dl, K-padding columns left alone) against p (dp - sum dp p); and the same bits as
+    the one-wave-per-row kernels it replaces up to fp32 summation order."""
+    B, Lq, C = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + C)
+    logits = 3 * torch.randn(Lq * B, C, device=dev, generator=g)
+    recon = torch.full((B, Lq, C), float("nan"), device=dev)
+    ops.softmax_tb_fwd(logits, C, recon, B, Lq, C)
+    want = torch.softmax(logits.double(), dim=1).view(Lq, B, C).transpose(0, 1)
+    assert float((recon.double() - want).abs().max()) < 2e-6
+    assert torch.allclose(recon.sum(-1), torch.ones(B, Lq, device=dev), atol=1e-5)
+    drecon = torch.randn(B, Lq, C, device=dev, generator=g)
+    ldd = 128 if C <= 128 else 256
+    dl = torch.full((Lq * B + 8, ldd), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.softmax_tb_bwd(recon, drecon, dl[:Lq * B], None, B, Lq, C)
+    p64, d64 = recon.double(), drecon.double()
+    ref = (p64 * (d64 - (p64 * d64).sum(-1, keepdim=True))).transpose(0, 1).reshape(Lq * B, C)
+    got = dl[:Lq * B, :C].double()
+    assert float((got - ref).abs().max()) < 8e-3 * float(ref.abs().max()) + 1e-30      # bf16 rounding of the result
+    c8 = (C + 7) // 8 * 8
+    assert float(dl[:Lq * B, C:c8].abs().sum()) == 0.0                                   # zeroed up to the 16-byte chunk
+    assert bool((dl[Lq * B:] == 7.0).all())                                              # rows past the matrix untouched
+    monkeypatch.setenv("MVAE_SOFTMAX_TILED", "0")
+    recon0 = torch.empty_like(recon); dl0 = torch.zeros_like(dl)
+    ops.softmax_tb_fwd(logits, C, recon0, B, Lq, C)
+    ops.softmax_tb_bwd(recon, drecon, dl0[:Lq * B], None, B, Lq, C)
+    assert float((recon0 - recon).abs().max()) < 2e-6
+    assert float((dl0[:Lq * B, :C].float() - dl[:Lq * B, :C].float()).abs().max()) < 8e-3 * float(ref.abs().max())
+
+
+def test_single_launch_loss_is_deterministic_and_resets_its_ticket():
+    """mvae_bce_kl_loss_fwd as ONE launch (last-block-done): repeated calls on the same workspace give the same bits (the ticket counter
+    resets itself), soft targets take the general formula, sizes that are not a multiple of 4 / of the block count work, and the value
+    equals torch's BCELoss-based evaluation of train.py:31-38."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for n_rows, C in ((1024 * 120, 35), (7, 3), (300, 35)):
+        p = torch.softmax(torch.randn(n_rows, C, device=dev, generator=g), -1)
+        hard = torch.nn.functional.one_hot(torch.randint(0, C, (n_rows,), device=dev, generator=g), C).float()
+        soft = torch.rand(n_rows, C, device=dev, generator=g)
+        mu, lv = torch.randn(64, 292, device=dev, generator=g), torch.randn(64, 292, device=dev, generator=g)
+        for tgt in (hard, soft):
+            outs = []
+            for _ in range(3):
+                out = torch.full((3,), float("nan"), device=dev)
+                ops.bce_kl_loss_fwd(p, tgt, mu, lv, 120.0, out)
+                outs.append(out.clone())
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+            xent = 120.0 * torch.nn.functional.binary_cross_entropy(p.double(), tgt.double())
+            kl = -0.5 * torch.mean(1. + mu.double() - lv.double() ** 2 - torch.exp(mu.double()))
+            assert abs(float(outs[0][1]) - float(xent)) < 2e-6 * abs(float(xent)) and abs(float(outs[0][2]) - float(kl)) < 2e-6 * abs(float(kl))
+            assert abs(float(outs[0][0]) - float(xent + kl)) < 2e-6 * abs(float(xent + kl))
