@@ -107,6 +107,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the B=512 / b=128 / f32 secondary measurements (N = 1)")
     ap.add_argument("--cpu-steps", type=int, default=16)
+    ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: reduce-scatter + sharded clip/Adam + all-gather instead of all-reduce")
+    ap.add_argument("--grad-compress", default=None, choices=[None, "bf16"], help="N > 1: all-reduce the gradient as bfloat16")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the multi-rank "
                                                        "path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -140,7 +142,7 @@ class MolVaeWorkload:
             self.name = self.name.replace("i=120,o=292,c=35", f"i={L},o=292,c={C}").replace("[B,120,35]", f"[B,{L},{C}]")
         torch.manual_seed(42)                                     # train.py:73
         self.model = mv.MolecularVAE(i=L, o=LATENT, c=C, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev)
-        self.optimizer = mv.FusedAdam(self.model.parameters(), lr=0.0008, max_grad_norm=3.0, grad_sync=sync)   # train.py:81,102
+        self.optimizer = mv.FusedAdam(self.model.parameters(), lr=0.0008, max_grad_norm=3.0, grad_sync=sync, shard_optimizer=bool(getattr(sync, "shard_optimizer", False)))   # train.py:81,102
         self.loss_function = mv.make_loss_function(L)
         self.n_params = sum(p.numel() for p in self.model.parameters())
         g = torch.Generator().manual_seed(1234 + rank)
@@ -260,7 +262,7 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
         dt = float(t)
     ms = 1e3 * dt / steps
     log(f"[{label}] timed region done: {ms:.2f} ms/step")
-    tag_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in prof.items()}
+    tag_ms = {k: sum(s.elapsed_time(e) for s, e in v) / steps for k, v in prof.items()}      # per STEP (a tag may be recorded several times in one)
     roof = wl.roofline(tag_ms, dtype)
     roof["phase_ms"] = {k: round(v, 3) for k, v in tag_ms.items()}
     comm = None
@@ -269,7 +271,8 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
         # overlap with backward did NOT hide.  MAX over ranks, like the step time.
         t = torch.tensor([tag_ms.get("dp_allreduce_exposed", 0.0)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        comm = dict(allreduce_exposed_ms=round(float(t), 3), world_size_reported=dist.get_world_size(), backend=dist.get_backend(),
+        comm = dict(allreduce_exposed_ms=round(float(t), 3), form=("reduce-scatter + sharded clip/Adam + all-gather" if getattr(sync, "shard_optimizer", False) else
+                                                                  "all-reduce, early ranges from inside backward") + (", bf16 on the wire" if sync.compress else ""), world_size_reported=dist.get_world_size(), backend=dist.get_backend(),
                     gradient_bytes=4 * getattr(wl, "n_params", 0), early_ranges_per_step=(sync.stats["early_ranges"] / max(1, steps + warmup)) if sync else 0)
     roof["whole_step_tflops"] = round(wl.flops_per_step() * steps / dt / 1e12, 2)
     res = dict(value=round(B * world * steps / dt, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup, dtype=dtype,
@@ -310,7 +313,8 @@ def main():
         if dist.get_world_size() != args.gpus:
             die(f"{dist.get_world_size()} ranks joined, --gpus {args.gpus}")
         import molecular_vae_amd as mv
-        sync = mv.GradSync()
+        sync = mv.GradSync(compress=args.grad_compress)
+        sync.shard_optimizer = args.shard_optimizer
     if args.batch > 0:
         B, scaling = args.batch, "weak"
     else:

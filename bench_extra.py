@@ -21,7 +21,7 @@ class MosesWorkload:
         self.V = len(v)
         torch.manual_seed(42)
         self.model = MV.VAE(v, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev).train()
-        self.optimizer = mv.FusedAdam(self.model.parameters(), lr=3e-4, max_grad_norm=50.0, grad_sync=sync)
+        self.optimizer = mv.FusedAdam(self.model.parameters(), lr=3e-4, max_grad_norm=50.0, grad_sync=sync, shard_optimizer=bool(getattr(sync, "shard_optimizer", False)))
         rs = np.random.RandomState(1234 + rank)
         lens = np.clip(np.rint(rs.normal(38, 8, size=B)), 10, 57).astype(int)
         lens = np.sort(lens)[::-1]
@@ -74,7 +74,7 @@ class Models2dWorkload:
         self.mv, self.B = mv, B
         torch.manual_seed(42)
         self.model = M2.VAE(dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev).train()
-        self.optimizer = mv.FusedAdam(self.model.parameters(), lr=8e-4, max_grad_norm=3.0, grad_sync=sync)
+        self.optimizer = mv.FusedAdam(self.model.parameters(), lr=8e-4, max_grad_norm=3.0, grad_sync=sync, shard_optimizer=bool(getattr(sync, "shard_optimizer", False)))
         self.loss_function = mv.make_loss_function(120)
         g = torch.Generator().manual_seed(1234 + rank)
         idx = torch.randint(0, 35, (B, 120), generator=g).to(dev)

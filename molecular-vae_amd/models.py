@@ -697,11 +697,26 @@ class _DecoderFn(torch.autograd.Function):
                     dG, dstate, ldg=ldg, tag="dec_lstm_bwd", dy_a=(dl if fuse_dy else None), dy_w=(P["WoutT"] if fuse_dy else None),
                     dy_k=(_dyk(Cv) if fuse_dy else 0))
 
-        def weight_grads(part):
-            """Everything that only produces parameter gradients (nothing on the path to dz): output head + LSTM weights.
-            part 0: head + the upper layers; part 1: the two lowest layers (parked for the peer, see below); None: everything."""
-            with ops._Timed("dec_lstm_wgrad" if part != 1 else "dec_lstm_wgrad_deferred"):
-                if part != 1:
+        # Everything that only produces parameter gradients (nothing on the path to dz) -- the output head + the LSTM weights -- is cut into
+        # PARTS, each a set of layers whose gradients are one contiguous range of the flat gradient buffer, produced (and, in DP, all-reduced)
+        # in reverse layer order.  Default: two parts (head + the upper layers | the two lowest layers: 256 / 192 tiles of the grouped GEMM, one
+        # round of workgroups each).  Data parallel (an optimiser with a GradSync that takes early ranges): ONE PART PER LAYER, so that layer
+        # 3's range is on the links while layers 2, 1, 0 are still being contracted and the encoder's backward runs -- four early ranges
+        # instead of two (at the per-rank batch of a DP job the 128-tile launches cost little: K = T * b is short).
+        gsync = getattr(sink[0], "grad_sync", None) if sink is not None else None
+        dp_early = gsync is not None and gsync.world > 1 and gsync.allow_early
+        nlow = min(int(os.environ.get("MVAE_DEFER_LAYERS", "2")), NL - 1)
+        per_layer = os.environ.get("MVAE_WGRAD_PER_LAYER", "1" if dp_early else "0") == "1"
+        if per_layer:
+            parts = [[l] for l in range(NL - 1, -1, -1)]
+        else:
+            parts = [list(range(nlow, NL))] + ([list(range(nlow))] if nlow >= 1 else [])
+        first_name = lambda l: f"gru.weight_ih_l{l}" if l >= 1 else "gru.weight_hh_l0"
+
+        def weight_grads(k):
+            """part k of `parts` (None: everything at once, on the current stream)."""
+            with ops._Timed("dec_lstm_wgrad" if (k is None or k == 0) else "dec_lstm_wgrad_deferred"):
+                if k is None or k == 0:
                     if dt == torch.bfloat16:
                         ops.gemm_tn(dl, hs[-1].view(TB, ldh), grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldl, ldb=ldh)
                         dbp = W("dbout_p", (Cp,))
@@ -712,26 +727,22 @@ class _DecoderFn(torch.autograd.Function):
                         ops.cast_transpose(hs[-1].view(TB, ldh), TB, H, dstT=hsT, lds=ldh)
                         ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
                         ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
-                nlow = min(int(os.environ.get("MVAE_DEFER_LAYERS", "2")), NL - 1)
-                layers = range(NL) if part is None else (range(nlow, NL) if part == 0 else range(nlow))
+                layers = range(NL) if k is None else parts[k]
                 _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers)
-                if part is not None and sink is not None and getattr(sink[0], "grad_sync", None) is not None:
-                    # What this part produced is final on this stream: all-reduce it now.  Part 0 (upper layers + head: everything from
-                    # gru.weight_ih_l{nlow} to the end of our range) then travels under the SECOND group of weight-gradient GEMMs and the
-                    # encoder's backward; part 1 ([gru.weight_hh_l0, gru.weight_ih_l{nlow})) under whatever is left of the encoder's
-                    # backward.  weight_ih_l0 / latent_input, produced on the main stream later, go with the rest in step().
-                    # Fork path only: there the gradients are handed over by ASSIGNMENT (p.grad = view of the flat buffer), so what
-                    # step() sees is the reduced buffer; through autograd's AccumulateGrad a clone could hide it (FusedAdam.gather_grads)
-                    first_hi = f"gru.weight_ih_l{nlow}" if nlow >= 1 else "gru.weight_hh_l0"
-                    if part == 0:
-                        sink[0].grad_sync.start_early(sink[1], sink[2] + offs[first_hi], sink[3])
-                    elif nlow >= 1:
-                        sink[0].grad_sync.start_early(sink[1], sink[2] + offs["gru.weight_hh_l0"], sink[2] + offs[first_hi])
+                if k is not None and dp_early:
+                    # What this part produced is final on this stream: all-reduce it now -- [first parameter of its lowest layer, start of
+                    # the previous part) (part 0: to the end of our range, i.e. with the head).  weight_ih_l0 / latent_input, produced on
+                    # the main stream later, go with the rest in step().  Fork path only: there the gradients are handed over by ASSIGNMENT
+                    # (p.grad = view of the flat buffer), so what step() sees is the reduced buffer; through autograd's AccumulateGrad a
+                    # clone could hide it (FusedAdam.gather_grads)
+                    lo = sink[2] + offs[first_name(min(parts[k]))]
+                    hi = sink[3] if k == 0 else sink[2] + offs[first_name(min(parts[k - 1]))]
+                    gsync.start_early(sink[1], lo, hi)
 
         # Fork: the weight-gradient GEMMs are throughput-bound and independent of dz, while the encoder's backward that follows is a
         # latency-bound chain of small launches -> run them concurrently.  Only when our MolecularVAE peer will join the side stream
         # (its backward ends with ForkState.join) and no gradient accumulation is pending (p.grad is assigned, never added to).
-        # The two lowest layers' GEMMs are parked (ops.ForkState): the peer releases them right before its row-resident LSTM backward,
+        # The later parts are parked (ops.ForkState): the peer releases them right before its row-resident LSTM backward,
         # whose 128 workgroups leave half the CUs idle -- the GEMMs fill them instead of running alone later.
         peer = mod.__dict__["_peer"]() if mod.__dict__["_peer"] is not None else None
         fork = bool(mod.overlap_weight_grads and peer is not None and ctx.from_peer and ctx.needs_input_grad[1] and
@@ -740,8 +751,8 @@ class _DecoderFn(torch.autograd.Function):
             side = mod._side_stream(dev)
             gflat.record_stream(side)
             fstate = peer.__dict__["_fork"]                               # the model's own fork state (ops.ForkState), kept by the peer
-            fstate.park(side, lambda: weight_grads(0), 0)                 # released by the peer after its head section
-            fstate.park(side, lambda: weight_grads(1), 1)                 # released next to the peer's row-resident LSTM backward
+            for k in range(len(parts)):                                   # first half: released by the peer after its head section; the rest
+                fstate.park(side, (lambda kk=k: weight_grads(kk)), 0 if 2 * k < len(parts) else 1)   # next to its row-resident LSTM backward
         else:
             weight_grads(None)
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]

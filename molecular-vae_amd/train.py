@@ -29,12 +29,19 @@ class GradSync:
     per-link transfer well above the latency floor while letting bucket k+1 overlap bucket k's reduction.
     """
 
-    def __init__(self, bucket_bytes=32 << 20, group=None, early=True):
+    def __init__(self, bucket_bytes=32 << 20, group=None, early=True, compress=None):
+        """compress="bf16": every bucket is all-reduced as bfloat16 (rounded copy out, sum, converted back into the fp32 buffer): half the
+        bytes on the links, ~3 significant digits per gradient element -- what the bf16 training mode's decoder gradients carry anyway; the
+        optimiser still accumulates in fp32.  None: fp32 on the wire (bit-reproducible sums)."""
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.group = group
         self.allow_early = early  # False: every range is reduced in step() (needed when parameter hooks clone gradients)
+        self.compress = compress
         self.handles = []
         self.early = []          # [(flat, lo, hi)] ranges whose all-reduce was started from inside backward (this step)
+        self._staged = []        # compress: (fp32 view, bf16 copy) pairs to convert back in wait()
         self.stats = dict(buckets=0, early_ranges=0)     # running totals (tests / logs)
 
     @property
@@ -47,8 +54,12 @@ class GradSync:
         n = flat.numel()
         for off in range(0, n, self.bucket_elems):
             self.stats["buckets"] += 1
-            self.handles.append(dist.all_reduce(flat[off:min(n, off + self.bucket_elems)], op=dist.ReduceOp.SUM,
-                                                group=self.group, async_op=True))
+            piece = flat[off:min(n, off + self.bucket_elems)]
+            if self.compress == "bf16":
+                half = piece.to(torch.bfloat16)               # plumbing: a rounded copy for the wire
+                self._staged.append((piece, half))
+                piece = half
+            self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def start_early(self, flat, lo, hi):
         """Called from a module's backward once flat[lo:hi] is final on the CURRENT stream (the collective is ordered after
@@ -74,8 +85,32 @@ class GradSync:
     def wait(self):
         for h in self.handles:
             h.wait()
-        self.handles = []
-        self.early = []
+        for piece, half in self._staged:
+            piece.copy_(half)
+        self.handles, self.early, self._staged = [], [], []
+
+    # -- sharded form: reduce-scatter -> every rank updates its 1/world of the flat buffers -> all-gather of the parameters
+    def reduce_scatter(self, flat, shard_elems):
+        """flat [world * shard_elems] -> this rank's reduced shard (a view of `flat`): half the bytes of an all-reduce on every link."""
+        w, r = self.world, dist.get_rank(self.group)
+        assert flat.numel() == w * shard_elems
+        out = flat[r * shard_elems:(r + 1) * shard_elems]
+        self.stats["buckets"] += 1
+        if out.device.type == "cpu":                           # gloo: no in-place aliasing of input and output
+            tmp = torch.empty_like(out)
+            dist.reduce_scatter_tensor(tmp, flat, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(tmp)
+        else:
+            dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def all_gather(self, flat, shard_elems):
+        """every rank's shard of `flat` (its own slice, updated in place) -> the whole buffer on every rank."""
+        r = dist.get_rank(self.group)
+        mine = flat[r * shard_elems:(r + 1) * shard_elems]
+        if flat.device.type == "cpu":
+            mine = mine.clone()
+        dist.all_gather_into_tensor(flat, mine, group=self.group)
 
     def grad_scale(self):
         return 1.0 / self.world
@@ -124,10 +159,19 @@ class FusedAdam(torch.optim.Optimizer):
     _ADAM_INERT = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                        decoupled_weight_decay=False)
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, grad_sync=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, grad_sync=None, shard_optimizer=False):
+        """shard_optimizer (needs a GradSync with world > 1): the gradient is reduce-SCATTERED, every rank runs the clip + Adam update on its
+        1/world slice of the flat buffers only (exp_avg / exp_avg_sq of the other slices stay untouched: `gather_state()` collects them
+        before a checkpoint), and the updated parameters are all-gathered -- half the collective bytes of the all-reduce form and 1/world
+        of the 7 x 4 x P bytes of optimiser traffic.  The global gradient norm is formed from the same 64K-element partial sums in the same
+        order as the all-reduce form, so both forms give bit-identical parameters.  No early (in-backward) ranges in this form."""
         defaults = dict(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, **self._ADAM_INERT)
         super().__init__(params, defaults)
         self.grad_sync = grad_sync
+        self.shard = bool(shard_optimizer) and grad_sync is not None and grad_sync.world > 1
+        if self.shard:
+            grad_sync.allow_early = False
+        world = grad_sync.world if self.shard else 1
         self._flat = []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
@@ -136,7 +180,11 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             dev = ps[0].device
             n = sum(p.numel() for p in ps)
-            pflat = torch.empty(n, dtype=torch.float32, device=dev)
+            # sharded form: equal slices whose boundaries fall on the 64K-element chunks of the gradient-norm partial sums (zero padding)
+            chunk = 1 << 16
+            shard_elems = ((n + world * chunk - 1) // (world * chunk)) * chunk if self.shard else n
+            n_alloc = shard_elems * world
+            pflat = torch.zeros(n_alloc, dtype=torch.float32, device=dev)
             m = torch.zeros_like(pflat); v = torch.zeros_like(pflat); g = torch.zeros_like(pflat)
             off = 0
             for p in ps:
@@ -147,9 +195,9 @@ class FusedAdam(torch.optim.Optimizer):
                 self.state[p] = dict(step=torch.tensor(0.0), exp_avg=m[off:off + k].view(p.shape),
                                      exp_avg_sq=v[off:off + k].view(p.shape))
                 off += k
-            nparts = (n + (1 << 16) - 1) >> 16
+            nparts = (n_alloc + (1 << 16) - 1) >> 16
             self._flat.append(dict(params=ps, p=pflat, m=m, v=v, g=g, partial=torch.zeros(nparts, device=dev),
-                                   norm=torch.zeros(1, device=dev), step=0))
+                                   norm=torch.zeros(1, device=dev), step=0, n=n, shard_elems=shard_elems))
             off = 0
             for p in ps:                 # modules may write their gradients straight into g (see _lib.register_grad_sink)
                 L.register_grad_sink(p, self, g, off)
@@ -193,7 +241,7 @@ class FusedAdam(torch.optim.Optimizer):
         ops.join_pending()             # gradients produced on a side stream (decoder weight-gradient GEMMs)
         flats = self.gather_grads()
         sync = self.grad_sync
-        if sync is not None:
+        if sync is not None and not self.shard:
             with ops._Timed("dp_allreduce_exposed" if sync.world > 1 else None):   # bench.py: what the overlap with backward did not hide
                 for g in flats:
                     sync.start_rest(g)
@@ -208,14 +256,38 @@ class FusedAdam(torch.optim.Optimizer):
                 raise L.MvaeError("FusedAdam implements plain Adam (train.py:81): weight_decay / amsgrad / maximize are not supported")
             if f["p"].device.type != "cuda":
                 raise L.MvaeError("FusedAdam.step runs on the MI355X only (no CPU fallback)")
-            with ops._Timed("hbm_sumsq_clip_adam"):
-                ops.sumsq(f["g"], f["partial"])
-                ops.clip_adam(f["p"], f["g"], f["m"], f["v"], f["partial"], scale, group["max_grad_norm"], group["lr"], b1, b2,
-                              group["eps"], f["step"], f["norm"])
+            if self.shard:
+                S, r = f["shard_elems"], dist.get_rank(sync.group)
+                with ops._Timed("dp_allreduce_exposed"):
+                    gs = sync.reduce_scatter(f["g"], S)
+                sl = slice(r * S, (r + 1) * S)
+                cps = S >> 16                                         # 64K-element chunks per shard: this rank's slice of the partial sums
+                with ops._Timed("hbm_sumsq_clip_adam"):
+                    f["partial"].zero_()
+                    ops.sumsq(gs, f["partial"][r * cps:(r + 1) * cps])
+                    dist.all_reduce(f["partial"], group=sync.group)    # disjoint slices + zeros: a gather, a few KB; same values on every rank
+                    ops.clip_adam(f["p"][sl], gs, f["m"][sl], f["v"][sl], f["partial"], scale, group["max_grad_norm"], group["lr"], b1, b2,
+                                  group["eps"], f["step"], f["norm"])
+                with ops._Timed("dp_allreduce_exposed"):
+                    sync.all_gather(f["p"], S)
+            else:
+                with ops._Timed("hbm_sumsq_clip_adam"):
+                    ops.sumsq(f["g"], f["partial"])
+                    ops.clip_adam(f["p"], f["g"], f["m"], f["v"], f["partial"], scale, group["max_grad_norm"], group["lr"], b1, b2,
+                                  group["eps"], f["step"], f["norm"])
             for p in f["params"]:
                 self.state[p]["step"] += 1
         L.PARAM_EPOCH[0] += 1      # packed bf16 / transposed weight shadows must be refreshed
         return loss
+
+    def gather_state(self):
+        """Sharded form: every rank holds the Adam moments of its own slice only; collect all of them (before ``state_dict()`` / a checkpoint)."""
+        if not self.shard:
+            return
+        for f in self._flat:
+            if f is not None:
+                self.grad_sync.all_gather(f["m"], f["shard_elems"])
+                self.grad_sync.all_gather(f["v"], f["shard_elems"])
 
     def load_state_dict(self, state_dict):
         """Accepts a FusedAdam or a ``torch.optim.Adam`` state dict (train.py:173 ``optimizer_state_dict``): same ``state`` layout

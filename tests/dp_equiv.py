@@ -21,6 +21,8 @@ ap.add_argument("--b", type=int, default=64)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32: re-association noise only (sharp check); bf16: the bench configuration")
 ap.add_argument("--model", default="molvae", choices=["molvae", "moses"])
+ap.add_argument("--shard", action="store_true", help="world > 1: reduce-scatter + sharded clip / Adam + all-gather (FusedAdam(shard_optimizer=True))")
+ap.add_argument("--compress", default=None, choices=[None, "bf16"], help="world > 1: gradient all-reduce as bfloat16")
 args = ap.parse_args()
 if args.compare:
     a, b = (json.load(open(f)) for f in args.compare)
@@ -74,8 +76,8 @@ if args.model == "moses":
 L_SEQ, VOCAB, LATENT = 120, 35, 292
 torch.manual_seed(42)
 model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
-sync = mv.GradSync() if world > 1 else None
-opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0, grad_sync=sync)
+sync = mv.GradSync(compress=args.compress) if world > 1 else None
+opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0, grad_sync=sync, shard_optimizer=args.shard)
 loss_fn = mv.make_loss_function(L_SEQ)
 g = torch.Generator().manual_seed(7)
 gb = 2 * args.b
@@ -100,6 +102,12 @@ for s in range(args.steps):
     out["gnorm"].append(float(opt.last_grad_norm))
     out["psum"].append(float(sum(p.detach().abs().sum() for p in model.parameters())))
 out["early_ranges"] = sync.stats["early_ranges"] if sync is not None else 0
+out["pcheck"] = [float(p.detach().double().sum()) for p in list(model.parameters())[:6]] + [float(opt.state[next(iter(model.decoder.gru.parameters()))]["exp_avg"].double().abs().sum())]
+if args.shard and world > 1:
+    opt.gather_state()
+    out["mcheck"] = float(sum(opt.state[p]["exp_avg"].double().abs().sum() for p in model.parameters()))
+elif world >= 1:
+    out["mcheck"] = float(sum(opt.state[p]["exp_avg"].double().abs().sum() for p in model.parameters()))
 if rank == 0 and args.out:
     json.dump(out, open(args.out, "w"))
     print(out)

@@ -35,6 +35,20 @@ def _worker(rank, world, port, out_dir):
     sync.start_early(flat, 100, 200)
     sync.start_rest(flat); sync.wait()
     assert torch.equal(flat, expect) and sync.early == [] and sync.handles == []
+    # 1c) bf16 on the wire: values that are exact in bfloat16 survive exactly; others are rounded once per rank
+    sync16 = mv.GradSync(bucket_bytes=4 * 1000, compress="bf16")
+    flat = torch.arange(2048, dtype=torch.float32).remainder(64) * (rank + 1)
+    sync16.start(flat); sync16.wait()
+    assert torch.equal(flat, torch.arange(2048, dtype=torch.float32).remainder(64) * sum(r + 1 for r in range(world))) and sync16._staged == []
+    # 1d) the sharded form's collectives: reduce-scatter leaves this rank's reduced slice in place, all-gather rebuilds the whole buffer
+    S = 4096
+    flat = torch.arange(world * S, dtype=torch.float32) * (rank + 1)
+    mine = sync.reduce_scatter(flat, S)
+    want = torch.arange(world * S, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    assert mine.data_ptr() == flat[rank * S:].data_ptr() and torch.equal(mine, want[rank * S:(rank + 1) * S])
+    mine.mul_(0.5)                                            # "the update" on this rank's slice
+    sync.all_gather(flat, S)
+    assert torch.equal(flat, 0.5 * want)
     # 2) per-shard oracle gradients, all-reduced and scaled, equal the global-batch gradients
     shapes = ip.molvae_shapes(G1["i"], G1["o"], G1["c"], G1["emb"], G1["h_enc"], G1["n_enc"], G1["h_dec"], G1["n_dec"])
     p = ip.init_params(shapes, G1["seed"], G1["gain"], np.float64)
