@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 5
+#define MVAE_ABI_VERSION 6
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -331,7 +331,9 @@ int mvae_expand_indices(const uint8_t* store, const int64_t* rows, int B, int L,
  *     w.r.t. the returned logits was added to dl, those rows are cleared before mvae_rnn_bwd contracts dl as dy_a (the decoder_fc weight /
  *     bias gradients are taken from the unmasked dl first).
  */
-int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* stream);
+size_t mvae_moses_latent_workspace(int B);     /* one float per sequence: per-row KL sums, added up in a fixed order */
+int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* ws, size_t ws_bytes,
+                          void* stream);
 int mvae_moses_latent_bwd(int B, int dz, const float* mu, const float* logvar, const float* eps, const float* dz_in, const float* dkl,
                           const float* dlogvar_ext, float* dmu, float* dlogvar, void* stream);
 size_t mvae_ce_loss_workspace(int B, int T);

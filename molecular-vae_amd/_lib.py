@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # run with any MVAE_* variable set, so a measured number always comes from the product library.
 LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MVAE_F32, MVAE_BF16, MVAE_F32X3 = 0, 1, 2
 CONV_BWD_X3 = 0x100
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
@@ -112,7 +112,8 @@ SIGNATURES = {
     "mvae_bce_kl_loss_fwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "mvae_bce_kl_loss_bwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "mvae_expand_indices": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "mvae_moses_latent_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_moses_latent_workspace": (_sz, [_i]),
+    "mvae_moses_latent_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mvae_moses_latent_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvae_ce_loss_workspace": (_sz, [_i, _i]),
     "mvae_ce_loss_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),

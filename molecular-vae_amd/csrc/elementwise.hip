@@ -817,37 +817,28 @@ __global__ __launch_bounds__(256) void permute102_kernel(int T_, int B, int V, c
   }
 }
 // z = mu + exp(logvar/2) * eps ; kl = 0.5 * mean_b sum_j (exp(logvar) + mu^2 - 1 - logvar)      (mosesvae.py:158-162)
-__global__ __launch_bounds__(1024) void moses_latent_fwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z,
-                                                                float* kl_out) {
-  // single block (deterministic order; B*dz is small, <= a few 1e5) of 1024 threads, four independent elements in flight per thread
-  __shared__ float red[16];
-  const long n = (long)B * dz;
-  float a[4] = {0.f, 0.f, 0.f, 0.f};
-  for (long i0 = threadIdx.x; i0 < n; i0 += 4096) {
-    float m[4], lv[4], e[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long i = i0 + 1024 * u;
-      const bool ok = i < n;
-      m[u] = ok ? mu[i] : 0.f; lv[u] = ok ? logvar[i] : 0.f; e[u] = ok ? eps[i] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long i = i0 + 1024 * u;
-      if (i < n) {
-        z[i] = m[u] + expf(lv[u] * 0.5f) * e[u];
-        a[u] += expf(lv[u]) + m[u] * m[u] - 1.f - lv[u];
-      }
-    }
+// one wave per sequence (row): z for the row, the row's KL sum to row_kl[b]; a second tiny launch adds the rows up in a fixed order.  (The
+// single 1024-thread block this replaces walked all B * dz elements by itself: 54 us at B = 1024 -- pure latency.)
+__global__ __launch_bounds__(256) void moses_latent_fwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z,
+                                                               float* row_kl) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float a = 0.f;
+  for (int j = lane; j < dz; j += 64) {
+    const long i = (long)b * dz + j;
+    const float m = mu[i], lv = logvar[i];
+    z[i] = m + expf(lv * 0.5f) * eps[i];
+    a += expf(lv) + m * m - 1.f - lv;
   }
-  float v = wave_sum((a[0] + a[1]) + (a[2] + a[3]));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += red[w];
-    kl_out[0] = 0.5f * t / (float)B;
-  }
+  a = wave_sum(a);
+  if (lane == 0) row_kl[b] = a;
+}
+__global__ __launch_bounds__(256) void moses_latent_kl_kernel(int B, const float* row_kl, float* kl_out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) a += row_kl[i];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) kl_out[0] = 0.5f * a / (float)B;
 }
 __global__ __launch_bounds__(256) void moses_latent_bwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps,
                                                                const float* dzv, const float* dkl, const float* dlogvar_ext, float* dmu, float* dlogvar) {
@@ -860,34 +851,41 @@ __global__ __launch_bounds__(256) void moses_latent_bwd_kernel(int B, int dz, co
   }
 }
 // token cross-entropy of mosesvae.py:193-197: logits row (t*B+b) predicts x[b, t+1]; targets == pad are ignored; mean over the rest.
-// one wave per (t, b) row; partial[(row)] = nll or 0, cnt likewise; reduced in fixed order by the final kernel.
+// a block = 64 consecutive (t, b) rows, 16 per wave; per-BLOCK partial sums (nll, count), added up in a fixed order by the final kernel.
+// (One partial per row made the final kernel a 66 us serial walk over T * B * 2 floats by one block.)
+constexpr int CE_RPB = 64;
 __global__ __launch_bounds__(256) void ce_tb_fwd_kernel(int B, int T_, int V, const float* logits, long ldl, const int64_t* x, int pad,
                                                         float* nll, float* cnt) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= (long)B * T_) return;
-  const int t = (int)(row / B), b = (int)(row - (long)t * B);
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long rows = (long)B * T_;
   float out = 0.f, c = 0.f;
-  if (t + 1 < T_) {
+  for (int k = 0; k < CE_RPB / 4; ++k) {
+    const long row = (long)blockIdx.x * CE_RPB + w * (CE_RPB / 4) + k;
+    if (row >= rows) break;                                  // wave-uniform
+    const int t = (int)(row / B), b = (int)(row - (long)t * B);
+    if (t + 1 >= T_) continue;
     const long tgt = x[(long)b * T_ + t + 1];
-    if (tgt != pad) {
-      const float* l = logits + row * ldl;
-      float mx = -INFINITY;
-      for (int v = lane; v < V; v += 64) mx = fmaxf(mx, l[v]);
-      mx = wave_max(mx);
-      float s = 0.f;
-      for (int v = lane; v < V; v += 64) s += expf(l[v] - mx);
-      s = wave_sum(s);
-      out = mx + logf(s) - l[tgt];
-      c = 1.f;
-    }
+    if (tgt == pad) continue;
+    const float* l = logits + row * ldl;
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, l[v]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(l[v] - mx);
+    s = wave_sum(s);
+    out += mx + logf(s) - l[tgt];
+    c += 1.f;
   }
-  if (lane == 0) { nll[row] = out; cnt[row] = c; }
+  // every lane of a wave holds the same (out, c): one value per wave into the block sum
+  const float o4 = block_sum_256(lane == 0 ? out : 0.f, red);
+  const float c4 = block_sum_256(lane == 0 ? c : 0.f, red);
+  if (threadIdx.x == 0) { nll[blockIdx.x] = o4; cnt[blockIdx.x] = c4; }
 }
-__global__ __launch_bounds__(256) void ce_tb_final_kernel(long rows, const float* nll, const float* cnt, float* out2) {
+__global__ __launch_bounds__(256) void ce_tb_final_kernel(long nparts, const float* nll, const float* cnt, float* out2) {
   __shared__ float red[4];
   float a = 0.f, c = 0.f;
-  for (long i = threadIdx.x; i < rows; i += 256) { a += nll[i]; c += cnt[i]; }
+  for (long i = threadIdx.x; i < nparts; i += 256) { a += nll[i]; c += cnt[i]; }
   a = block_sum_256(a, red);
   c = block_sum_256(c, red);
   if (threadIdx.x == 0) { out2[0] = a / c; out2[1] = c; }
@@ -1064,9 +1062,14 @@ int mvae_permute102(int T, int B, int V, const float* in, float* out, void* stre
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
-int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* stream) {
+size_t mvae_moses_latent_workspace(int B) { return (size_t)(B > 0 ? B : 0) * sizeof(float); }
+int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* ws, size_t ws_bytes,
+                          void* stream) {
   if (!mu || !logvar || !eps || !z || !kl_out || B < 1 || dz < 1) return MVAE_ERR_INVALID;
-  hipLaunchKernelGGL(moses_latent_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, dz, mu, logvar, eps, z, kl_out);
+  if (!ws || ws_bytes < mvae_moses_latent_workspace(B)) return MVAE_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(moses_latent_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, dz, mu, logvar, eps, z, (float*)ws);
+  hipLaunchKernelGGL(moses_latent_kl_kernel, dim3(1), dim3(256), 0, st, B, (const float*)ws, kl_out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
@@ -1083,11 +1086,11 @@ int mvae_ce_loss_fwd(int B, int T, int V, const float* logits, int64_t ldl, cons
                      void* stream) {
   if (!logits || !x || !loss2 || B < 1 || T < 1 || V < 1) return MVAE_ERR_INVALID;
   if (!ws || ws_bytes < mvae_ce_loss_workspace(B, T)) return MVAE_ERR_WORKSPACE;
-  const long rows = (long)B * T;
-  float* nll = (float*)ws; float* cnt = nll + rows;
+  const long rows = (long)B * T, nparts = (rows + CE_RPB - 1) / CE_RPB;
+  float* nll = (float*)ws; float* cnt = nll + nparts;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_tb_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, B, T, V, logits, (long)ldl, x, pad, nll, cnt);
-  hipLaunchKernelGGL(ce_tb_final_kernel, dim3(1), dim3(256), 0, st, rows, (const float*)nll, (const float*)cnt, loss2);
+  hipLaunchKernelGGL(ce_tb_fwd_kernel, dim3((unsigned)nparts), dim3(256), 0, st, B, T, V, logits, (long)ldl, x, pad, nll, cnt);
+  hipLaunchKernelGGL(ce_tb_final_kernel, dim3(1), dim3(256), 0, st, nparts, (const float*)nll, (const float*)cnt, loss2);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

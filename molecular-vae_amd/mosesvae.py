@@ -15,6 +15,8 @@ gradients enabled) takes the token mean of the reconstruction loss (mosesvae.py:
 (``dp_global_token_mean``, one 4-byte all-reduce on ``dp_group``), so that the all-reduced gradient equals the single-process gradient of
 the global batch; eval / no_grad forwards never communicate.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -71,6 +73,12 @@ class VAE(nn.Module, _SavedState):
         self.compute_dtype = dtype
         self._init_saved_state()
         self._pack_key, self._packed = None, {}
+        self.__dict__["_side"] = None
+
+    def _side_stream(self, dev):
+        if self.__dict__["_side"] is None:
+            self.__dict__["_side"] = torch.cuda.Stream(device=dev)
+        return self.__dict__["_side"]
 
     @property
     def device(self):
@@ -358,8 +366,19 @@ class _MosesFn(torch.autograd.Function):
         ops.ce_loss_bwd(y_tb, V, x_pad, mod.pad, loss2, g1(drecon), c(dy_ext), dl, B, T, V)
         hsx_d = [W(f"dec_hsx{l}", (T + 1, B, ldh_d), dt) for l in range(NL)]
         out_seq = hsx_d[-1][1:].reshape(TB, ldh_d)
-        _kmajor_gemm(ws, "fc", dl, ldl, V, out_seq, ldh_d, Hd, TB, grads["decoder_fc.weight"], dev)
-        dbp = W("dbfc_p", (Vp8,)); ops.colsum_t(dl, TB, Vp8, dbp, ldx=ldl); grads["decoder_fc.bias"].copy_(dbp[:V])
+        # Everything below that only produces PARAMETER gradients of the decoder (decoder_fc, the GRU stack's dW / db, the token table) is
+        # throughput-bound and independent of dz, while what follows on the path to the encoder -- heads, the encoder GRU's reverse
+        # wavefront: ~120 dependent launches of a few microseconds, a fraction of the chip each -- is latency-bound: the former runs on a side
+        # stream beside the latter (joined before the gradients are handed to autograd).  MVAE_MOSES_FORK=0: one stream (A/B knob).
+        fork = os.environ.get("MVAE_MOSES_FORK", "1") != "0" and dy_ext is None
+        side = mod._side_stream(dev) if fork else None
+
+        def fc_grads():
+            _kmajor_gemm(ws, "fc", dl, ldl, V, out_seq, ldh_d, Hd, TB, grads["decoder_fc.weight"], dev)
+            dbp = W("dbfc_p", (Vp8,)); ops.colsum_t(dl, TB, Vp8, dbp, ldx=ldl); grads["decoder_fc.bias"].copy_(dbp[:V])
+
+        if not fork:
+            fc_grads()
         if fuse_dy and dy_ext is not None:
             # an external gradient w.r.t. the returned logits sits in dl at finished positions too (it counts for decoder_fc.bias, above); the
             # padded output carries no gradient back to h there (pad_packed_sequence, mosesvae.py:189), and the top cell contracts dl AS IS:
@@ -381,33 +400,50 @@ class _MosesFn(torch.autograd.Function):
                     drop_p=(drop[0] if drop else 0.0), drop_seed=(drop[1] if drop else 0), tag="moses_dec_bwd",
                     dy_a=(dl if fuse_dy else None), dy_w=(P["WfcT"] if fuse_dy else None), dy_k=(_dyk(V) if fuse_dy else 0))
         hd = [W(f"dec_hd{l}", (T, B, ldh_d), dt) for l in range(NL - 1)] if drop is not None else None
-        s4 = W("dec_s4", (4 * Hd,))
-        for l in range(NL):
-            a = dG_d[l].view(TB, ldg_d)
-            hprev = hsx_d[l][:T].reshape(TB, ldh_d)                  # h_{t-1} for every t (slot 0 = h_0)
-            gw = grads[f"decoder_rnn.weight_hh_l{l}"]
-            _kmajor_gemm(ws, "dwhh_rz", a, ldg_d, 2 * Hd, hprev, ldh_d, Hd, TB, gw[:2 * Hd], dev)
-            _kmajor_gemm(ws, "dwhh_n", a[:, 3 * Hd:], ldg_d, Hd, hprev, ldh_d, Hd, TB, gw[2 * Hd:], dev)
-            if l > 0:                                                 # the layer's input: the output of layer l-1 (after its dropout in train mode)
-                xin = hd[l - 1].view(TB, ldh_d) if hd is not None else hsx_d[l - 1][1:].reshape(TB, ldh_d)
-                _kmajor_gemm(ws, "dwih", a, ldg_d, 3 * Hd, xin, ldh_d, Hd, TB, grads[f"decoder_rnn.weight_ih_l{l}"], dev)
-            ops.colsum_t(a, TB, 4 * Hd, s4, ldx=ldg_d)
-            grads[f"decoder_rnn.bias_ih_l{l}"].copy_(s4[:3 * Hd])
-            grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
-        # layer-0 input = [emb(x_t), z]: table scatter for the embedding part, time sum for the z part
-        dtbl3 = W("dec_dtbl3", (V, 3 * Hd))
         onehot = None
         if dt == torch.bfloat16:
-            # scatter as a contraction: dtbl = onehot(x)^T . dG0 over the T*B rows -- one TN GEMM that streams the bf16 gradient once
+            # the token scatter as a contraction: dtbl = onehot(x)^T . dG0 over the T*B rows (the encoder's table gradient reuses the matrix)
             onehot = W("onehot_tb", (TB + 8, Vp8), dt)[:TB]
             ops.onehot_tb(x_pad, onehot, B, T, V)
-            ops.gemm_tn(onehot, dG_d[0].view(TB, ldg_d), dtbl3, V, 3 * Hd, TB, lda=Vp8, ldb=ldg_d)
+        dE = W("dE", (V, V))
+
+        def dec_weight_grads():
+            s4 = W("dec_s4", (4 * Hd,))
+            for l in range(NL):
+                a = dG_d[l].view(TB, ldg_d)
+                hprev = hsx_d[l][:T].reshape(TB, ldh_d)                  # h_{t-1} for every t (slot 0 = h_0)
+                gw = grads[f"decoder_rnn.weight_hh_l{l}"]
+                _kmajor_gemm(ws, "dwhh_rz", a, ldg_d, 2 * Hd, hprev, ldh_d, Hd, TB, gw[:2 * Hd], dev)
+                _kmajor_gemm(ws, "dwhh_n", a[:, 3 * Hd:], ldg_d, Hd, hprev, ldh_d, Hd, TB, gw[2 * Hd:], dev)
+                if l > 0:                                                 # the layer's input: the output of layer l-1 (after its dropout in train mode)
+                    xin = hd[l - 1].view(TB, ldh_d) if hd is not None else hsx_d[l - 1][1:].reshape(TB, ldh_d)
+                    _kmajor_gemm(ws, "dwih", a, ldg_d, 3 * Hd, xin, ldh_d, Hd, TB, grads[f"decoder_rnn.weight_ih_l{l}"], dev)
+                ops.colsum_t(a, TB, 4 * Hd, s4, ldx=ldg_d)
+                grads[f"decoder_rnn.bias_ih_l{l}"].copy_(s4[:3 * Hd])
+                grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
+            # layer-0 input = [emb(x_t), z]: table gradient for the embedding part (the z part is on the path to the encoder: main stream)
+            dtbl3 = W("dec_dtbl3", (V, 3 * Hd))
+            if onehot is not None:
+                ops.gemm_tn(onehot, dG_d[0].view(TB, ldg_d), dtbl3, V, 3 * Hd, TB, lda=Vp8, ldb=ldg_d)
+            else:
+                dtbl4 = W("dec_dtbl4", (V, 4 * Hd)); ops.scatter_rows_tb(x_pad, dG_d[0], dtbl4, B, T, V, 4 * Hd, ldd=ldg_d)
+                dtbl3.copy_(dtbl4[:, :3 * Hd])
+            ops.gemm_nt(dtbl3, pd["WxT"], dE, V, V, 3 * Hd)
+            dtblT = W("dec_dtblT", (3 * Hd, Vp)); ops.cast_transpose(dtbl3, V, 3 * Hd, dstT=dtblT)
+            dwx = W("dec_dwx", (3 * Hd, V)); ops.gemm_nt(dtblT, P["ET_p"], dwx, 3 * Hd, V, Vp)
+            grads["decoder_rnn.weight_ih_l0"][:, :V].copy_(dwx)
+
+        side_done = None
+        if fork:
+            ev = torch.cuda.Event(); ev.record()
+            side.wait_event(ev)
+            gflat.record_stream(side)
+            with torch.cuda.stream(side):
+                fc_grads()
+                dec_weight_grads()
+                side_done = torch.cuda.Event(); side_done.record()
         else:
-            dtbl4 = W("dec_dtbl4", (V, 4 * Hd)); ops.scatter_rows_tb(x_pad, dG_d[0], dtbl4, B, T, V, 4 * Hd, ldd=ldg_d)
-            dtbl3.copy_(dtbl4[:, :3 * Hd])
-        dE = W("dE", (V, V)); ops.gemm_nt(dtbl3, pd["WxT"], dE, V, V, 3 * Hd)
-        dtblT = W("dec_dtblT", (3 * Hd, Vp)); ops.cast_transpose(dtbl3, V, 3 * Hd, dstT=dtblT)
-        dwx = W("dec_dwx", (3 * Hd, V)); ops.gemm_nt(dtblT, P["ET_p"], dwx, 3 * Hd, V, Vp)
+            dec_weight_grads()
         dzp4 = W("dzp4", (B, ldg_d)); ops.timesum(dG_d[0], T, B, ldg_d, dzp4)
         dzp3 = W("dzp3", (B, 3 * Hd)); dzp3.copy_(dzp4[:, :3 * Hd])
         z = W("z_saved", (B, dz))      # filled below from mu/lv/eps (z is recomputed: it was an output tensor)
@@ -416,7 +452,7 @@ class _MosesFn(torch.autograd.Function):
         dzp3T, zT = W("dzp3T", (3 * Hd, Bp)), W("zT", (dz, Bp))
         ops.cast_transpose(dzp3, B, 3 * Hd, dstT=dzp3T); ops.cast_transpose(z, B, dz, dstT=zT)
         dwz = W("dec_dwz", (3 * Hd, dz)); ops.gemm_nt(dzp3T, zT, dwz, 3 * Hd, dz, Bp)
-        gw0 = grads["decoder_rnn.weight_ih_l0"]; gw0[:, :V].copy_(dwx); gw0[:, V:].copy_(dwz)
+        grads["decoder_rnn.weight_ih_l0"][:, V:].copy_(dwz)          # (the token columns [:, :V] are written by dec_weight_grads)
         dz_tot = W("dz_tot", (B, dz)); ops.gemm_nt(dzp3, P["WzT"], dz_tot, B, dz, 3 * Hd)
         # h_0 = decoder_lat(z), shared by the layers
         dh0s = dh0[0]
@@ -463,6 +499,8 @@ class _MosesFn(torch.autograd.Function):
         dE2 = W("dE2", (V, V)); ops.gemm_nt(etbl3, pe["WxT"], dE2, V, V, 3 * Hq)
         etblT = W("enc_dtblT", (3 * Hq, Vp)); ops.cast_transpose(etbl3, V, 3 * Hq, dstT=etblT)
         ops.gemm_nt(etblT, P["ET_p"], grads["encoder_rnn.weight_ih_l0"], 3 * Hq, V, Vp)
+        if side_done is not None:
+            torch.cuda.current_stream().wait_event(side_done)        # the decoder's parameter gradients (and dE) from the side stream
         ge = grads["x_emb.weight"]; torch.add(dE, dE2, out=ge)
         ge[mod.pad].zero_()                                           # nn.Embedding(padding_idx=pad): no gradient to the pad row
         return (None, None, None, None, None) + tuple(grads[n] for n in names)

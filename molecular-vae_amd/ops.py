@@ -234,7 +234,10 @@ def permute102(inp, out, T, B, V):
 
 
 def moses_latent_fwd(mu, logvar, eps, z, kl, B, dz):
-    check(L.load().mvae_moses_latent_fwd(B, dz, ptr(mu), ptr(logvar), ptr(eps), ptr(z), ptr(kl), stream_ptr()), "mvae_moses_latent_fwd")
+    lib = L.load()
+    need = lib.mvae_moses_latent_workspace(B)
+    ws = Scratch.get(need, mu.device)
+    check(lib.mvae_moses_latent_fwd(B, dz, ptr(mu), ptr(logvar), ptr(eps), ptr(z), ptr(kl), ptr(ws), need, stream_ptr()), "mvae_moses_latent_fwd")
 
 
 def moses_latent_bwd(mu, logvar, eps, dz_in, dkl, dlogvar_ext, dmu, dlogvar, B, dz):
