@@ -51,7 +51,7 @@ extern "C" {
 #define MVAE_MAX_LAYERS 8
 
 int mvae_abi_version(void);
-/* sizeof of the descriptor structs as THIS library was compiled (0: mvae_rnn_fwd_desc, 1: mvae_rnn_bwd_desc, 2: mvae_gemm_tn_problem;
+/* sizeof of the descriptor structs as THIS library was compiled (0: mvae_rnn_fwd_desc, 1: mvae_rnn_bwd_desc, 2: mvae_gemm_tn_problem, 3: mvae_pack_job;
  * anything else: 0) -- a binding checks its own mirror of the structs against it at load time. */
 size_t mvae_struct_size(int which);
 const char* mvae_status_string(int status);
@@ -109,6 +109,22 @@ int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const v
  * its transpose) and activation transposes. */
 int mvae_cast_transpose(int dtype_src, int dtype_dst, int R, int C, const void* src, int64_t lds_,
                         void* dst, int64_t ldd, void* dstT, int64_t ldt, void* stream);
+
+/* Multi-tensor pack: a LIST of small packing jobs in one launch (a model refreshes dozens of weight shadows after every optimiser step:
+ * fp32 master -> bf16 / zero-padded / transposed copies, bias sums, block copies -- each a few-microsecond launch of its own otherwise).
+ *   kind 0: dst[r, c] and / or dstT[c, r] = (dst_dtype) src[r, c] for r < R, c < C only (no zero fill of padding: allocate destinations zeroed);
+ *   kind 1: dst[i] = src[i] + src2[i], fp32, R * C elements (b_ih + b_hh);   kind 2: dst[r, c] = src[r, c], fp32, leading dimensions lds / ldd.
+ * `jobs_device` is an array in DEVICE memory (build it once: the pointers do not change from step to step); block0 = index of the job's
+ * first block = sum of mvae_pack_job_blocks() of the jobs before it; total_blocks = the sum over all jobs.  Jobs must not overlap. */
+typedef struct {
+  int kind, src_dtype, dst_dtype, R, C, block0;
+  const void* src; int64_t lds;
+  void* dst; int64_t ldd;
+  void* dstT; int64_t ldt;
+  const void* src2;
+} mvae_pack_job;
+int mvae_pack_job_blocks(const mvae_pack_job* job);
+int mvae_pack_multi(int njobs, const mvae_pack_job* jobs_device, int total_blocks, void* stream);
 
 /* out[n, b, a] = in[n, a, b] (fp32): the channel-major Flatten of models.py:6-10 <-> the conv GEMM's row order. */
 int mvae_permute021(int N, int A, int Bd, const float* in, float* out, void* stream);

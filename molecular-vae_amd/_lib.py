@@ -65,6 +65,11 @@ class GemmTnProblem(C.Structure):
                 ("C", _vp), ("ldc", _i64), ("accumulate", _i), ("colsum_out", _vp), ("colsum_accumulate", _i)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("kind", _i), ("src_dtype", _i), ("dst_dtype", _i), ("R", _i), ("C", _i), ("block0", _i),
+                ("src", _vp), ("lds", _i64), ("dst", _vp), ("ldd", _i64), ("dstT", _vp), ("ldt", _i64), ("src2", _vp)]
+
+
 # name -> (restype, argtypes); mirrors include/mvae.h one to one (tests check every symbol is exported)
 SIGNATURES = {
     "mvae_abi_version": (_i, []),
@@ -75,6 +80,8 @@ SIGNATURES = {
     "mvae_gemm_tn_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_gemm_tn": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "mvae_cast_transpose": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "mvae_pack_job_blocks": (_i, [C.POINTER(PackJob)]),
+    "mvae_pack_multi": (_i, [_i, _vp, _i, _vp]),
     "mvae_permute021": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "mvae_gather_rows_tb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
@@ -149,7 +156,7 @@ def load():
         fn.argtypes = args
     if lib.mvae_abi_version() != ABI_VERSION:
         raise MvaeError("libmvae_hip.so ABI version mismatch")
-    for which, st in enumerate((RnnFwdDesc, RnnBwdDesc, GemmTnProblem)):
+    for which, st in enumerate((RnnFwdDesc, RnnBwdDesc, GemmTnProblem, PackJob)):
         if lib.mvae_struct_size(which) != C.sizeof(st):
             raise MvaeError(f"{st.__name__}: ctypes mirror is {C.sizeof(st)} bytes, the library's struct {lib.mvae_struct_size(which)}")
     _lib = lib

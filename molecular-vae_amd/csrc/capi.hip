@@ -14,6 +14,7 @@ size_t mvae_struct_size(int which) {
     case 0: return sizeof(mvae_rnn_fwd_desc);
     case 1: return sizeof(mvae_rnn_bwd_desc);
     case 2: return sizeof(mvae_gemm_tn_problem);
+    case 3: return sizeof(mvae_pack_job);
     default: return 0;
   }
 }

@@ -1404,6 +1404,10 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
       const long fused_tiles = (long)((B + 63) / 64) * ((H + 63) / 64) * NL;
       const long kcols = (gru && tune_int("MVAE_GRU3", 1) ? 6L : 8L) * H;
       if (fused_tiles >= 192 && 128 * kcols * sz <= (1L << 20)) { nsplit = 0; BM = 64; BN = 64; }
+      // A ONE-layer stack (the MOSES encoder GRU(256)): a cell is a few hundred KB of operands either way, and every time step of the
+      // split form is two dependent launches (GEMM + element-wise) of ~7 us each, i.e. launch latency twice: the fused single launch wins
+      // (MOSES B = 1024: 6.56 -> 6.26 ms / step, in-situ A/B)
+      if (NL == 1 && 128 * kcols * sz <= (1L << 20)) { nsplit = 0; BM = 64; BN = 64; }
     }
   }
   const bool big_fused = nsplit == 1;            // (128 x 128, unsplit): the wave-specialised kernel with the gate-derivative epilogue fused

@@ -325,61 +325,72 @@ class MolEncoder(nn.Module, _SavedState):
         self.lmbd.mu, self.lmbd.log_v = mu, logv
         return z, mu, logv
 
-    # -- packed weight shadows (refreshed when any parameter changed)
+    # -- packed weight shadows (refreshed when any parameter changed): ONE multi-tensor pack launch (ops.PackList) + the three conv packs
     def _pack(self, dev):
         params = list(self.parameters())
         key = _params_key(params)
         if key == self._pack_key:
             return self._packed
-        g, ws = self.gru, self._ws
-        H, NL, E, Cv = g.hidden_size, g.num_layers, g.input_size, self.embedding.num_embeddings
-        P = {}
+        ptrs = (dev,) + tuple(p.data_ptr() for p in params)
+        if self.__dict__.get("_pack_ptrs") != ptrs:
+            self._build_pack(dev)
+            self.__dict__["_pack_ptrs"] = ptrs
         with torch.no_grad():
-            Ep = _pad(E, 4)
-            P["E_p"] = ws.get("E_p", (Cv, Ep), torch.float32, dev)
-            ops.cast_transpose(self.embedding.weight, Cv, E, dst=P["E_p"])
-            P["ET"] = ws.get("ET", (E, _pad(Cv, 4)), torch.float32, dev)
-            ops.cast_transpose(self.embedding.weight, Cv, E, dstT=P["ET"])
-            P["Wih0_p"] = ws.get("Wih0_p", (4 * H, Ep), torch.float32, dev)
-            P["Wih0T"] = ws.get("Wih0T", (E, 4 * H), torch.float32, dev)
-            ops.cast_transpose(g.weight_ih_l0, 4 * H, E, dst=P["Wih0_p"], dstT=P["Wih0T"])
-            P["bias"] = []
-            P["WihT"], P["WhhT"] = [None], []
-            Hp = _pad(H, 32)                       # whole 128-byte K-steps (f32): zero-padded shadows -> LDS-direct main loop
-            P["Hp"] = Hp
-            P["Wih"], P["Whh"] = [None], []
-            for l in range(NL):
-                b = ws.get(f"bias{l}", (4 * H,), torch.float32, dev)
-                torch.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), out=b)
-                P["bias"].append(b)
-                w = ws.get(f"Whh{l}", (4 * H, Hp), torch.float32, dev)
-                t = ws.get(f"WhhT{l}", (H, 4 * H), torch.float32, dev)
-                ops.cast_transpose(getattr(g, f"weight_hh_l{l}"), 4 * H, H, dst=w, dstT=t)
-                P["Whh"].append(w); P["WhhT"].append(t)
-                if l > 0:
-                    w = ws.get(f"Wih{l}", (4 * H, Hp), torch.float32, dev)
-                    t = ws.get(f"WihT{l}", (H, 4 * H), torch.float32, dev)
-                    ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), 4 * H, H, dst=w, dstT=t)
-                    P["Wih"].append(w); P["WihT"].append(t)
-            # conv stack, channels-last with channel counts padded to whole K-steps: packed weights for the sliding-window GEMMs
+            self.__dict__["_pack_list"].run()
             for n, conv in (("c1", self.conv_1[0]), ("c2", self.conv_2[0]), ("c3", self.conv_3[0])):
                 Ci, Co, k = conv.in_channels, conv.out_channels, conv.kernel_size
-                ldx, ldo = _pad(Ci, 32), _pad(Co, 32)
-                P[n + "_wp"] = ws.get(n + "_wp", (Co, k * ldx), torch.float32, dev)
-                P[n + "_wq"] = ws.get(n + "_wq", (Ci, k * ldo), torch.float32, dev)
-                ops.conv1d_pack_weights(conv.weight, Ci, Co, k, ldx, P[n + "_wp"], ldo, P[n + "_wq"])
-            d1 = self.dense_1[0]
-            P["W1T"] = ws.get("W1T", (d1.in_features, d1.out_features), torch.float32, dev)
-            ops.cast_transpose(d1.weight, d1.out_features, d1.in_features, dstT=P["W1T"])
-            o = self.lmbd.z_mean.out_features
-            P["Wml"] = ws.get("Wml", (2 * o, 512), torch.float32, dev)
-            P["Wml"][:o].copy_(self.lmbd.z_mean.weight); P["Wml"][o:].copy_(self.lmbd.z_log_var.weight)
-            P["bml"] = ws.get("bml", (2 * o,), torch.float32, dev)
-            P["bml"][:o].copy_(self.lmbd.z_mean.bias); P["bml"][o:].copy_(self.lmbd.z_log_var.bias)
-            P["WmlT"] = ws.get("WmlT", (512, _pad(2 * o, 4)), torch.float32, dev)
-            ops.cast_transpose(P["Wml"], 2 * o, 512, dstT=P["WmlT"])
-        self._pack_key, self._packed = key, P
-        return P
+                ops.conv1d_pack_weights(conv.weight, Ci, Co, k, _pad(Ci, 32), self._packed[n + "_wp"], _pad(Co, 32), self._packed[n + "_wq"])
+        self._pack_key = key
+        return self._packed
+
+    def _build_pack(self, dev):
+        """Allocate the shadows (zeroed: padding is never written) and record the jobs that fill them, each straight from a parameter."""
+        g, ws = self.gru, self._ws
+        H, NL, E, Cv = g.hidden_size, g.num_layers, g.input_size, self.embedding.num_embeddings
+        P, pl = {}, ops.PackList()
+        Ep = _pad(E, 4)
+        P["E_p"] = ws.get("E_p", (Cv, Ep), torch.float32, dev)
+        P["ET"] = ws.get("ET", (E, _pad(Cv, 4)), torch.float32, dev)
+        pl.cast_transpose(self.embedding.weight, Cv, E, dst=P["E_p"], dstT=P["ET"])
+        P["Wih0_p"] = ws.get("Wih0_p", (4 * H, Ep), torch.float32, dev)
+        P["Wih0T"] = ws.get("Wih0T", (E, 4 * H), torch.float32, dev)
+        pl.cast_transpose(g.weight_ih_l0, 4 * H, E, dst=P["Wih0_p"], dstT=P["Wih0T"])
+        P["bias"] = []
+        P["WihT"], P["WhhT"] = [None], []
+        Hp = _pad(H, 32)                       # whole 128-byte K-steps (f32): zero-padded shadows -> LDS-direct main loop
+        P["Hp"] = Hp
+        P["Wih"], P["Whh"] = [None], []
+        for l in range(NL):
+            b = ws.get(f"bias{l}", (4 * H,), torch.float32, dev)
+            pl.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), b)
+            P["bias"].append(b)
+            w = ws.get(f"Whh{l}", (4 * H, Hp), torch.float32, dev)
+            t = ws.get(f"WhhT{l}", (H, 4 * H), torch.float32, dev)
+            pl.cast_transpose(getattr(g, f"weight_hh_l{l}"), 4 * H, H, dst=w, dstT=t)
+            P["Whh"].append(w); P["WhhT"].append(t)
+            if l > 0:
+                w = ws.get(f"Wih{l}", (4 * H, Hp), torch.float32, dev)
+                t = ws.get(f"WihT{l}", (H, 4 * H), torch.float32, dev)
+                pl.cast_transpose(getattr(g, f"weight_ih_l{l}"), 4 * H, H, dst=w, dstT=t)
+                P["Wih"].append(w); P["WihT"].append(t)
+        # conv stack, channels-last with channel counts padded to whole K-steps: packed weights for the sliding-window GEMMs
+        for n, conv in (("c1", self.conv_1[0]), ("c2", self.conv_2[0]), ("c3", self.conv_3[0])):
+            Ci, Co, k = conv.in_channels, conv.out_channels, conv.kernel_size
+            ldx, ldo = _pad(Ci, 32), _pad(Co, 32)
+            P[n + "_wp"] = ws.get(n + "_wp", (Co, k * ldx), torch.float32, dev)
+            P[n + "_wq"] = ws.get(n + "_wq", (Ci, k * ldo), torch.float32, dev)
+        d1 = self.dense_1[0]
+        P["W1T"] = ws.get("W1T", (d1.in_features, d1.out_features), torch.float32, dev)
+        pl.cast_transpose(d1.weight, d1.out_features, d1.in_features, dstT=P["W1T"])
+        o = self.lmbd.z_mean.out_features
+        P["Wml"] = ws.get("Wml", (2 * o, 512), torch.float32, dev)
+        P["bml"] = ws.get("bml", (2 * o,), torch.float32, dev)
+        P["WmlT"] = ws.get("WmlT", (512, _pad(2 * o, 4)), torch.float32, dev)
+        for k, lin in enumerate((self.lmbd.z_mean, self.lmbd.z_log_var)):           # the stacked mu | logvar head and its transpose, each from the parameter
+            pl.cast_transpose(lin.weight, o, 512, dst=P["Wml"][k * o:(k + 1) * o], dstT=P["WmlT"][:, k * o:(k + 1) * o])
+            pl.copy(lin.bias, P["bml"][k * o:(k + 1) * o])
+        self._packed = P
+        self.__dict__["_pack_list"] = pl
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -569,38 +580,48 @@ class MolDecoder(nn.Module, _SavedState):
         key = _params_key(params) + (self.compute_dtype,)
         if key == self._pack_key:
             return self._packed
+        ptrs = (dev, self.compute_dtype) + tuple(p.data_ptr() for p in params)
+        if self.__dict__.get("_pack_ptrs") != ptrs:
+            self._build_pack(dev)
+            self.__dict__["_pack_ptrs"] = ptrs
+        with torch.no_grad():
+            self.__dict__["_pack_list"].run()          # every shadow in ONE launch (ops.PackList)
+        self._pack_key = key
+        return self._packed
+
+    def _build_pack(self, dev):
         g, ws, dt = self.gru, self._ws, self.compute_dtype
         H, NL, o = g.hidden_size, g.num_layers, g.input_size
         G4 = 4 * H
         f32 = torch.float32
         ldw, ldwT = H + _LDPAD, G4 + _LDPAD       # leading dimensions kept off powers of two (L2 / MALL set conflicts)
         P = {"Wih": [None], "WihT": [None], "Whh": [], "WhhT": [], "bias": [], "ldw": ldw, "ldwT": ldwT}
-        with torch.no_grad():
-            li = self.latent_input[0]
-            P["WliT"] = ws.get("WliT", (o, _pad(o, 4)), f32, dev)
-            ops.cast_transpose(li.weight, o, o, dstT=P["WliT"])
-            P["Wih0T"] = ws.get("Wih0T", (o, G4), f32, dev)
-            ops.cast_transpose(g.weight_ih_l0, G4, o, dstT=P["Wih0T"])
-            for l in range(NL):
-                b = ws.get(f"bias{l}", (G4,), f32, dev)
-                torch.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), out=b)
-                P["bias"].append(b)
-                w = ws.get(f"Whh{l}", (G4, ldw), dt, dev); wT = ws.get(f"WhhT{l}", (H, ldwT), dt, dev)
-                ops.cast_transpose(getattr(g, f"weight_hh_l{l}"), G4, H, dst=w, dstT=wT)
-                P["Whh"].append(w); P["WhhT"].append(wT)
-                if l > 0:
-                    w = ws.get(f"Wih{l}", (G4, ldw), dt, dev); wT = ws.get(f"WihT{l}", (H, ldwT), dt, dev)
-                    ops.cast_transpose(getattr(g, f"weight_ih_l{l}"), G4, H, dst=w, dstT=wT)
-                    P["Wih"].append(w); P["WihT"].append(wT)
-            om = self.decoded_mean.module[0]
-            Cv = om.out_features
-            Cp = _pad(Cv, 8)
-            P["Wout"] = ws.get("Wout", (Cv, H), dt, dev)
-            # bf16: W_out^T zero-padded to _dyk(C) columns -- the backward contracts the logit gradients with it inside the top LSTM cell
-            P["WoutT"] = ws.get("WoutT", (H, _dyk(Cv) if dt == torch.bfloat16 else Cp), dt, dev)
-            ops.cast_transpose(om.weight, Cv, H, dst=P["Wout"], dstT=P["WoutT"])
-        self._pack_key, self._packed = key, P
-        return P
+        pl = ops.PackList()
+        li = self.latent_input[0]
+        P["WliT"] = ws.get("WliT", (o, _pad(o, 4)), f32, dev)
+        pl.cast_transpose(li.weight, o, o, dstT=P["WliT"])
+        P["Wih0T"] = ws.get("Wih0T", (o, G4), f32, dev)
+        pl.cast_transpose(g.weight_ih_l0, G4, o, dstT=P["Wih0T"])
+        for l in range(NL):
+            b = ws.get(f"bias{l}", (G4,), f32, dev)
+            pl.add(getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"), b)
+            P["bias"].append(b)
+            w = ws.get(f"Whh{l}", (G4, ldw), dt, dev); wT = ws.get(f"WhhT{l}", (H, ldwT), dt, dev)
+            pl.cast_transpose(getattr(g, f"weight_hh_l{l}"), G4, H, dst=w, dstT=wT)
+            P["Whh"].append(w); P["WhhT"].append(wT)
+            if l > 0:
+                w = ws.get(f"Wih{l}", (G4, ldw), dt, dev); wT = ws.get(f"WihT{l}", (H, ldwT), dt, dev)
+                pl.cast_transpose(getattr(g, f"weight_ih_l{l}"), G4, H, dst=w, dstT=wT)
+                P["Wih"].append(w); P["WihT"].append(wT)
+        om = self.decoded_mean.module[0]
+        Cv = om.out_features
+        Cp = _pad(Cv, 8)
+        P["Wout"] = ws.get("Wout", (Cv, H), dt, dev)
+        # bf16: W_out^T zero-padded to _dyk(C) columns -- the backward contracts the logit gradients with it inside the top LSTM cell
+        P["WoutT"] = ws.get("WoutT", (H, _dyk(Cv) if dt == torch.bfloat16 else Cp), dt, dev)
+        pl.cast_transpose(om.weight, Cv, H, dst=P["Wout"], dstT=P["WoutT"])
+        self._packed = P
+        self.__dict__["_pack_list"] = pl
 
 
 class _DecoderFn(torch.autograd.Function):

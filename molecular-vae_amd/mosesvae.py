@@ -191,59 +191,72 @@ class VAE(nn.Module, _SavedState):
             return [xs[b, :ends[b]] for b in range(B)], z
         return [self.tensor2string(xs[b, :ends[b]]) for b in range(B)], z
 
-    # -- packed shadows
+    # -- packed shadows: ONE multi-tensor pack launch (ops.PackList) instead of ~60 few-microsecond launches per optimiser step
     def _pack(self, dev):
         params = self._plist()
         key = _params_key(params) + (self.compute_dtype,)
         if key == self._pack_key:
             return self._packed
+        ptrs = (dev, self.compute_dtype) + tuple(p.data_ptr() for p in params)
+        if self.__dict__.get("_pack_ptrs") != ptrs:
+            self._build_pack(dev)
+            self.__dict__["_pack_ptrs"] = ptrs
+        with torch.no_grad():
+            self.__dict__["_pack_list"].run()
+        self._pack_key = key
+        return self._packed
+
+    def _build_pack(self, dev):
+        """Allocate the shadows (zeroed: the empty gate slot of every 4-slot matrix and all padding are never written) and record the jobs
+        that fill them, each straight from a parameter (jobs of one launch must not depend on each other)."""
         ws, dt, f32 = self._ws, self.compute_dtype, torch.float32
         V = self.x_emb.num_embeddings
         Vp = _pad(V, 4)
-        P = {}
-        with torch.no_grad():
-            E = self.x_emb.weight
-            P["E_p"] = ws.get("E_p", (V, Vp), f32, dev); ops.cast_transpose(E, V, V, dst=P["E_p"])
-            P["ET_p"] = ws.get("ET_p", (V, Vp), f32, dev); ops.cast_transpose(E, V, V, dstT=P["ET_p"])
-            for name, rnn, nl in (("enc", self.encoder_rnn, 1), ("dec", self.decoder_rnn, self.decoder_rnn.num_layers)):
-                H = rnn.hidden_size
-                ldw, ldwT = H + _LDPAD, 4 * H + _LDPAD
-                P[name] = dict(H=H, ldw=ldw, ldwT=ldwT, Whh=[], WhhT=[], Wih=[None], WihT=[None], bias=[])
-                for l in range(nl):
-                    whh4 = _slots4(getattr(rnn, f"weight_hh_l{l}"), H, "h")
-                    w = ws.get(f"{name}_Whh{l}", (4 * H, ldw), dt, dev); wT = ws.get(f"{name}_WhhT{l}", (H, ldwT), dt, dev)
-                    ops.cast_transpose(whh4, 4 * H, H, dst=w, dstT=wT)
-                    P[name]["Whh"].append(w); P[name]["WhhT"].append(wT)
-                    if l > 0:
-                        wih4 = _slots4(getattr(rnn, f"weight_ih_l{l}"), H, "x")
-                        w = ws.get(f"{name}_Wih{l}", (4 * H, ldw), dt, dev); wT = ws.get(f"{name}_WihT{l}", (H, ldwT), dt, dev)
-                        ops.cast_transpose(wih4, 4 * H, H, dst=w, dstT=wT)
-                        P[name]["Wih"].append(w); P[name]["WihT"].append(wT)
-                    bi, bh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
-                    b4 = ws.get(f"{name}_bias{l}", (4 * H,), f32, dev)
-                    b4[:2 * H] = bi[:2 * H] + bh[:2 * H]; b4[2 * H:3 * H] = bi[2 * H:]; b4[3 * H:] = bh[2 * H:]
-                    P[name]["bias"].append(b4)
-                # layer-0 input weights: the embedding part becomes a table, the z part (decoder) a dense projection
-                w0 = getattr(rnn, "weight_ih_l0")
-                wx = ws.get(f"{name}_Wx_p", (3 * H, Vp), f32, dev); ops.cast_transpose(w0[:, :V].contiguous(), 3 * H, V, dst=wx)
-                wxT = ws.get(f"{name}_WxT", (V, 3 * H), f32, dev); ops.cast_transpose(w0[:, :V].contiguous(), 3 * H, V, dstT=wxT)
-                P[name]["Wx_p"], P[name]["WxT"] = wx, wxT
-            dz = self.d_z
-            Hd = P["dec"]["H"]
-            w0 = self.decoder_rnn.weight_ih_l0
-            P["Wz"] = ws.get("dec_Wz", (3 * Hd, dz), f32, dev); P["Wz"].copy_(w0[:, V:])
-            P["WzT"] = ws.get("dec_WzT", (dz, 3 * Hd), f32, dev); ops.cast_transpose(P["Wz"], 3 * Hd, dz, dstT=P["WzT"])
-            for n, seq in (("mu", self.q_mu), ("lv", self.q_logvar)):
-                P[n + "_W0T"] = ws.get(n + "_W0T", (seq[0].in_features, seq[0].out_features), f32, dev)
-                ops.cast_transpose(seq[0].weight, seq[0].out_features, seq[0].in_features, dstT=P[n + "_W0T"])
-                P[n + "_W2T"] = ws.get(n + "_W2T", (seq[2].in_features, seq[2].out_features), f32, dev)
-                ops.cast_transpose(seq[2].weight, seq[2].out_features, seq[2].in_features, dstT=P[n + "_W2T"])
-            P["WlatT"] = ws.get("WlatT", (dz, Hd), f32, dev); ops.cast_transpose(self.decoder_lat.weight, Hd, dz, dstT=P["WlatT"])
-            Vp8 = _pad(V, 8)
-            P["Wfc"] = ws.get("Wfc", (V, Hd + _LDPAD), dt, dev); P["WfcT"] = ws.get("WfcT", (Hd, _dyk(V) if dt == torch.bfloat16 else Vp8), dt, dev)
-            ops.cast_transpose(self.decoder_fc.weight, V, Hd, dst=P["Wfc"], dstT=P["WfcT"])
-        self._pack_key, self._packed = key, P
-        return P
+        P, pl = {}, ops.PackList()
+        E = self.x_emb.weight
+        P["E_p"] = ws.get("E_p", (V, Vp), f32, dev); P["ET_p"] = ws.get("ET_p", (V, Vp), f32, dev)
+        pl.cast_transpose(E, V, V, dst=P["E_p"], dstT=P["ET_p"])
+        for name, rnn, nl in (("enc", self.encoder_rnn, 1), ("dec", self.decoder_rnn, self.decoder_rnn.num_layers)):
+            H = rnn.hidden_size
+            ldw, ldwT = H + _LDPAD, 4 * H + _LDPAD
+            P[name] = dict(H=H, ldw=ldw, ldwT=ldwT, Whh=[], WhhT=[], Wih=[None], WihT=[None], bias=[])
+            for l in range(nl):
+                # gate rows (r, z, n) -> slots: W_hh (r, z, 0, n), W_ih (r, z, n, 0)
+                whh = getattr(rnn, f"weight_hh_l{l}")
+                w = ws.get(f"{name}_Whh{l}", (4 * H, ldw), dt, dev); wT = ws.get(f"{name}_WhhT{l}", (H, ldwT), dt, dev)
+                pl.cast_transpose(whh[:2 * H], 2 * H, H, dst=w[:2 * H], dstT=wT[:, :2 * H])
+                pl.cast_transpose(whh[2 * H:], H, H, dst=w[3 * H:], dstT=wT[:, 3 * H:4 * H])
+                P[name]["Whh"].append(w); P[name]["WhhT"].append(wT)
+                if l > 0:
+                    wih = getattr(rnn, f"weight_ih_l{l}")
+                    w = ws.get(f"{name}_Wih{l}", (4 * H, ldw), dt, dev); wT = ws.get(f"{name}_WihT{l}", (H, ldwT), dt, dev)
+                    pl.cast_transpose(wih, 3 * H, H, dst=w[:3 * H], dstT=wT[:, :3 * H])
+                    P[name]["Wih"].append(w); P[name]["WihT"].append(wT)
+                bi, bh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
+                b4 = ws.get(f"{name}_bias{l}", (4 * H,), f32, dev)
+                pl.add(bi[:2 * H], bh[:2 * H], b4[:2 * H]); pl.copy(bi[2 * H:], b4[2 * H:3 * H]); pl.copy(bh[2 * H:], b4[3 * H:])
+                P[name]["bias"].append(b4)
+            # layer-0 input weights: the embedding part becomes a table, the z part (decoder) a dense projection
+            w0 = getattr(rnn, "weight_ih_l0")
+            wx = ws.get(f"{name}_Wx_p", (3 * H, Vp), f32, dev); wxT = ws.get(f"{name}_WxT", (V, 3 * H), f32, dev)
+            pl.cast_transpose(w0[:, :V], 3 * H, V, dst=wx, dstT=wxT)
+            P[name]["Wx_p"], P[name]["WxT"] = wx, wxT
+        dz = self.d_z
+        Hd = P["dec"]["H"]
+        w0 = self.decoder_rnn.weight_ih_l0
+        P["Wz"] = ws.get("dec_Wz", (3 * Hd, dz), f32, dev); P["WzT"] = ws.get("dec_WzT", (dz, 3 * Hd), f32, dev)
+        pl.cast_transpose(w0[:, V:], 3 * Hd, dz, dst=P["Wz"], dstT=P["WzT"])
+        for n, seq in (("mu", self.q_mu), ("lv", self.q_logvar)):
+            P[n + "_W0T"] = ws.get(n + "_W0T", (seq[0].in_features, seq[0].out_features), f32, dev)
+            pl.cast_transpose(seq[0].weight, seq[0].out_features, seq[0].in_features, dstT=P[n + "_W0T"])
+            P[n + "_W2T"] = ws.get(n + "_W2T", (seq[2].in_features, seq[2].out_features), f32, dev)
+            pl.cast_transpose(seq[2].weight, seq[2].out_features, seq[2].in_features, dstT=P[n + "_W2T"])
+        P["WlatT"] = ws.get("WlatT", (dz, Hd), f32, dev); pl.cast_transpose(self.decoder_lat.weight, Hd, dz, dstT=P["WlatT"])
+        Vp8 = _pad(V, 8)
+        P["Wfc"] = ws.get("Wfc", (V, Hd + _LDPAD), dt, dev); P["WfcT"] = ws.get("WfcT", (Hd, _dyk(V) if dt == torch.bfloat16 else Vp8), dt, dev)
+        pl.cast_transpose(self.decoder_fc.weight, V, Hd, dst=P["Wfc"], dstT=P["WfcT"])
+        self._packed = P
+        self.__dict__["_pack_list"] = pl
 
 
 def _kmajor_gemm(ws, tag, A, lda, M, Bm, ldb, N, K, out, dev):
@@ -271,8 +284,7 @@ class _MosesFn(torch.autograd.Function):
         W = lambda name, shape, d=f32: ws.get(name, shape, d, dev)
         # ---------------- encoder GRU (mosesvae.py:150-156): embedding folded into a [V, 4H] table
         pe = P["enc"]; Hq = pe["H"]
-        tbl3 = W("enc_tbl3", (V, 3 * Hq)); ops.gemm_nt(P["E_p"], pe["Wx_p"], tbl3, V, 3 * Hq, Vp)
-        tbl4 = W("enc_tbl4", (V, 4 * Hq)); tbl4[:, :3 * Hq].copy_(tbl3)
+        tbl4 = W("enc_tbl4", (V, 4 * Hq)); ops.gemm_nt(P["E_p"], pe["Wx_p"], tbl4, V, 3 * Hq, Vp)      # slot 3 stays zero (ldc = 4H)
         # the table rows are added in the step epilogue (add_table / add_index): no gathered [T, B, 4H] copy
         ldh_e = Hq + _LDPAD
         hsx_e = [W("enc_hsx0", (T + 1, B, ldh_e), dt)]                 # slot 0 = initial state (zeros), slots 1.. = outputs
@@ -292,10 +304,8 @@ class _MosesFn(torch.autograd.Function):
         # ---------------- decoder (mosesvae.py:172-197)
         pd = P["dec"]; Hd = pd["H"]; NL = mod.decoder_rnn.num_layers
         h0 = W("h0", (B, Hd)); ops.gemm_nt(z, mod.decoder_lat.weight, h0, B, Hd, dz, bias=mod.decoder_lat.bias)
-        tbl3d = W("dec_tbl3", (V, 3 * Hd)); ops.gemm_nt(P["E_p"], pd["Wx_p"], tbl3d, V, 3 * Hd, Vp)
-        tbl4d = W("dec_tbl4", (V, 4 * Hd)); tbl4d[:, :3 * Hd].copy_(tbl3d)
-        zp3 = W("zp3", (B, 3 * Hd)); ops.gemm_nt(z, P["Wz"], zp3, B, 3 * Hd, dz)
-        zp4 = W("zp4", (B, 4 * Hd)); zp4[:, :3 * Hd].copy_(zp3)
+        tbl4d = W("dec_tbl4", (V, 4 * Hd)); ops.gemm_nt(P["E_p"], pd["Wx_p"], tbl4d, V, 3 * Hd, Vp)
+        zp4 = W("zp4", (B, 4 * Hd)); ops.gemm_nt(z, P["Wz"], zp4, B, 3 * Hd, dz)
         ldh_d = Hd + _LDPAD
         hsx_d = [W(f"dec_hsx{l}", (T + 1, B, ldh_d), dt) for l in range(NL)]
         for l in range(NL):
@@ -345,10 +355,9 @@ class _MosesFn(torch.autograd.Function):
         ldh_e, ldh_d = Hq + _LDPAD, Hd + _LDPAD
 
         def lin_bwd(tag, dy, x, WT, wname, bname, M_in, N_out, need_dx=True):
-            """y = x W^T + b:  dW = dy^T x, db = colsum(dy), dx = dy W (via the packed transpose WT [in, out])."""
-            dyT, xT = W(tag + "_dyT", (N_out, Bp)), W(tag + "_xT", (M_in, Bp))
-            ops.cast_transpose(dy, B, N_out, dstT=dyT); ops.cast_transpose(x, B, M_in, dstT=xT)
-            ops.gemm_nt(dyT, xT, grads[wname], N_out, M_in, Bp)
+            """y = x W^T + b:  dW = dy^T x (exact-f32 TN kernel straight from the batch-major operands), db = colsum(dy), dx = dy W (via the
+            packed transpose WT [in, out])."""
+            ops.gemm_tn(dy, x, grads[wname], N_out, M_in, B, lda=dy.stride(0), ldb=x.stride(0))
             ops.colsum(dy, B, N_out, grads[bname])
             if not need_dx:
                 return None

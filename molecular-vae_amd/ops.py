@@ -202,6 +202,67 @@ def cast_transpose(src, R, C_, dst=None, dstT=None, lds=None):
                                   ptr(dstT), dstT.stride(0) if dstT is not None else 0, stream_ptr()), "mvae_cast_transpose")
 
 
+class PackList:
+    """A list of weight-packing jobs run as ONE launch (mvae_pack_multi).  Build it once per set of buffers (`key`), call run() after every
+    optimiser step: the job table stays in device memory.  Methods mirror cast_transpose / torch.add / copy_; every tensor handed in must
+    stay alive and in place (parameters inside FusedAdam's flat buffer and workspace buffers do)."""
+
+    def __init__(self):
+        self.jobs, self.keep, self.table, self.total = [], [], None, 0
+
+    def _job(self, kind, src, R, C_, lds, dst=None, ldd=0, dstT=None, ldt=0, src2=None, dst_dtype=None):
+        j = L.PackJob()
+        j.kind, j.R, j.C = kind, R, C_
+        j.src_dtype = dt_code(src.dtype)
+        d = dst if dst is not None else dstT
+        j.dst_dtype = dt_code(d.dtype if dst_dtype is None else dst_dtype)
+        j.src, j.lds = src.data_ptr(), lds
+        j.dst, j.ldd = (dst.data_ptr() if dst is not None else None), ldd
+        j.dstT, j.ldt = (dstT.data_ptr() if dstT is not None else None), ldt
+        j.src2 = src2.data_ptr() if src2 is not None else None
+        self.jobs.append(j)
+        self.keep += [t for t in (src, dst, dstT, src2) if t is not None]
+        self.table = None
+
+    def cast_transpose(self, src, R, C_, dst=None, dstT=None, lds=None):
+        if R <= 0 or C_ <= 0:
+            return
+        if src.stride(-1) != 1 or (dst is not None and dst.stride(-1) != 1) or (dstT is not None and dstT.stride(-1) != 1):
+            raise L.MvaeError("PackList: innermost dimension must be contiguous")
+        self._job(0, src, R, C_, src.stride(0) if lds is None else lds, dst, dst.stride(0) if dst is not None else 0,
+                  dstT, dstT.stride(0) if dstT is not None else 0)
+
+    def add(self, a, b, out):
+        assert a.dtype == b.dtype == out.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+        self._job(1, a, 1, a.numel(), a.numel(), dst=out, ldd=out.numel(), src2=b)
+
+    def copy(self, src, dst):
+        """dst[r, c] = src[r, c] for 2-D (or 1-D) fp32 views with contiguous rows."""
+        assert src.dtype == dst.dtype == torch.float32 and src.shape == dst.shape
+        if src.dim() == 1:
+            src, dst = src.unsqueeze(0), dst.unsqueeze(0)
+        assert src.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+        self._job(2, src, src.shape[0], src.shape[1], src.stride(0) if src.shape[0] > 1 else src.shape[1],
+                  dst=dst, ldd=dst.stride(0) if dst.shape[0] > 1 else dst.shape[1])
+
+    def run(self):
+        if not self.jobs:
+            return
+        lib = L.load()
+        if self.table is None:
+            n = len(self.jobs)
+            arr = (L.PackJob * n)()
+            tot = 0
+            for i, j in enumerate(self.jobs):
+                j.block0 = tot
+                tot += lib.mvae_pack_job_blocks(C.byref(j))
+                arr[i] = j
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev = self.keep[0].device
+            self.table, self.total = host.to(dev), tot
+        check(lib.mvae_pack_multi(len(self.jobs), ptr(self.table), self.total, stream_ptr()), "mvae_pack_multi")
+
+
 def permute021(inp, out, N, A, Bd):
     check(L.load().mvae_permute021(N, A, Bd, ptr(inp), ptr(out), stream_ptr()), "mvae_permute021")
 

@@ -89,6 +89,7 @@ def test_forward_backward_bookkeeping_with_stubbed_kernels(monkeypatch):
                  "selu_bwd", "conv1d_pack_weights", "conv1d_selu_fwd", "conv1d_selu_bwd", "lambda_fwd", "lambda_bwd", "softmax_tb_fwd", "softmax_tb_bwd",
                  "rnn_fwd", "rnn_bwd"):
         monkeypatch.setattr(ops, name, stub(name))
+    monkeypatch.setattr(ops.PackList, "run", lambda self: calls.append("pack_multi"))      # the multi-tensor pack launch
     monkeypatch.setattr(M, "_require_cuda", lambda dev, what: None)
     enc = mv.MolEncoder(i=24, o=16, c=12, h_size=56, num_lstm=2)
     dec = mv.MolDecoder(i=16, o=24, c=12, num_gru=2, h_size=32, dtype=torch.float32)
@@ -100,6 +101,7 @@ def test_forward_backward_bookkeeping_with_stubbed_kernels(monkeypatch):
     for p in list(enc.parameters()) + list(dec.parameters()):
         assert p.grad is not None and p.grad.shape == p.shape
     assert calls.count("rnn_fwd") == 2 and calls.count("rnn_bwd") == 2 and calls.count("conv1d_selu_bwd") == 3
+    assert calls.count("pack_multi") == 2 and len(enc._pack_list.jobs) >= 10 and len(dec._pack_list.jobs) >= 8     # one pack launch per module
     # a second forward invalidates the saved workspace of the first
     z2, _, _ = enc(idx, torch.zeros(3, 16))
     z3, _, _ = enc(idx, torch.zeros(3, 16))
