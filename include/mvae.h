@@ -77,6 +77,12 @@ int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
                  void* C, int64_t ldc, int dtype_c, const float* bias, int act, int accumulate,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* fp32 (exact) form with the bias gradient:  C[M,N] (+)= A^T . B  and  colsum_out[m] (+)= sum_k A[k][m]  from the same MFMAs -- B gets a virtual
+ * column of ones at index N, in the slack of the last 64-wide tile (a whole extra tile column only when N % 64 == 0).  Replaces the
+ * mvae_gemm_tn + mvae_colsum pair behind every nn.Linear / nn.LSTM bias of the fp32 encoder.  ws >= mvae_gemm_tn_workspace(MVAE_F32). */
+int mvae_gemm_tn_f32_colsum(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
+                            float* colsum_out, int colsum_accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* bf16 weight gradient AND bias gradient from one pass over dG:  C[M,N] (+)= A^T . B  and  colsum_out[m] (+)= sum_k A[k][m].
  * The column sums come from ONE extra MFMA per wave and K-step (an A fragment against a fragment of ones) inside the 256 x 256-tile
  * kernel, shared out over the 16 waves that hold the same A rows, so they cost no extra HBM traffic (a separate mvae_colsum_t re-reads

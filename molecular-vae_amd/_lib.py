@@ -89,6 +89,7 @@ SIGNATURES = {
     "mvae_onehot_tb": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
     "mvae_dropout_keep": (_i, [C.c_uint32, C.c_uint32, _f]),
+    "mvae_gemm_tn_f32_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
     "mvae_gemm_tn_colsum_supported": (_i, [_i, _i, _i]),
     "mvae_gemm_tn_grouped_supported": (_i, [_i, _i, _i64, _i64, _i64]),
     "mvae_gemm_tn_grouped_workspace": (_sz, [_i, C.POINTER(GemmTnProblem)]),

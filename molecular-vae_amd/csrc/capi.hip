@@ -50,6 +50,12 @@ int mvae_gemm_tn(int dtype_ab, int M, int N, int K, const void* A, int64_t lda, 
   return launch_gemm_tn_bf16(M, N, K, A, lda, B, ldb, C, ldc, dtype_c, bias, act, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int mvae_gemm_tn_f32_colsum(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
+                            float* colsum_out, int colsum_accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (!colsum_out) return MVAE_ERR_INVALID;
+  return launch_gemm_tn_f32(M, N, K, A, lda, 0, 0, B, ldb, 0, 0, C, ldc, accumulate, ws, ws_bytes, (hipStream_t)stream, false, colsum_out, colsum_accumulate);
+}
+
 size_t mvae_gemm_tn_colsum_workspace(int M, int N, int K) { return gemm_tn_colsum_supported(M, N, K) ? gemm_tn_colsum_workspace_bytes(M, N, K) : 0; }
 int mvae_gemm_tn_colsum_supported(int M, int N, int K) { return gemm_tn_colsum_supported(M, N, K) ? 1 : 0; }
 int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int accumulate,

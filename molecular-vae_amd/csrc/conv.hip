@@ -130,10 +130,10 @@ int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, i
   int rc;
   hipLaunchKernelGGL(conv_dz_pad_kernel, dim3(cgrid((long)B * Wp * (ldo / 4))), dim3(256), 0, st, B, Wout, Cout, ldo, k, dy, y, dzp, act);
   MVAE_CHECK_HIP(hipGetLastError());
-  if ((rc = launch_colsum(B * Wp, Cout, dzp, ldo, db, gws, gws_bytes, st))) return rc;         // pad rows are zero
-  // dwp[o][kc] = sum over output positions of dz[(b,w)][o] * window(b,w)[kc]
+  // dwp[o][kc] = sum over output positions of dz[(b,w)][o] * window(b,w)[kc]; the bias gradient db[o] = sum over positions of dz[..][o] rides
+  // along as the GEMM's virtual ones column (the x3 form: ~16 mantissa bits, like the rest of that GEMM) -- no separate column-sum launches
   const float* dz0 = dzp + (long)(k - 1) * ldo;
-  if ((rc = launch_gemm_tn_f32(Cout, k * ldx, B * Wout, dz0, ldo, Wout, (long)Wp * ldo, x, ldx, Wout, x_bs, dwp, (long)k * ldx, 0, gws, gws_bytes, st, x3))) return rc;
+  if ((rc = launch_gemm_tn_f32(Cout, k * ldx, B * Wout, dz0, ldo, Wout, (long)Wp * ldo, x, ldx, Wout, x_bs, dwp, (long)k * ldx, 0, gws, gws_bytes, st, x3, db, 0))) return rc;
   hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3(cgrid((long)Cout * Cin * k)), dim3(256), 0, st, Cin, Cout, k, dwp, ldx, dw);
   MVAE_CHECK_HIP(hipGetLastError());
   if (dx) {

@@ -18,8 +18,10 @@ struct GemmArgs {
   // reads its im2col matrix straight out of the activation tensor.  a_total / b_total: elements in the operand buffer (bounds).
   int a_group, b_group;
   long a_gstride, b_gstride, a_total, b_total;
-  // TN 256 x 256 only: column sums of A (out[m] = sum_k A[k][m]) produced alongside C; per-split partials when splits > 1
-  float* colsum_out; float* colsum_partial; int colsum_acc;
+  // column sums of A (out[m] = sum_k A[k][m]) produced alongside C; per-split partials when splits > 1 (colsum_nparts of them: the bf16
+  // 256 x 256 kernel writes two K-halves per split, the f32 TN kernel one).  f32 TN kernel: the sums come from a virtual column of ONES
+  // appended to B at index ones_col = N (-1: none) -- C[m][N] = sum_k A[k][m] . 1 falls out of the same MFMAs, in the slack of the last tile
+  float* colsum_out; float* colsum_partial; int colsum_acc; int colsum_nparts; int ones_col;
 };
 __device__ __forceinline__ long grow(int r, int group, long gstride, long ld) {
   return group > 0 ? (long)(r / group) * gstride + (long)(r % group) * ld : (long)r * ld;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
   if (p.colsum_out && p.colsum_partial) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.M; i += (long)gridDim.x * 256) {
       float v = 0.f;
-      for (int s = 0; s < 2 * p.splits; ++s) v += p.colsum_partial[(long)s * p.M + i];      // (split, K-half) partials, fixed order
+      for (int s = 0; s < p.colsum_nparts; ++s) v += p.colsum_partial[(long)s * p.M + i];   // per-split (x K-half) partials, fixed order
       p.colsum_out[i] = p.colsum_acc ? p.colsum_out[i] + v : v;
     }
   }
@@ -358,7 +360,7 @@ int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long l
   p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
   p.a_group = a_group; p.a_gstride = a_gstride; p.a_total = a_total; p.b_group = 0; p.b_gstride = 0; p.b_total = (long)N * ldb;
-  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = 0;
+  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = 0; p.colsum_nparts = 0; p.ones_col = -1;
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
@@ -495,7 +497,7 @@ int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, con
   p.c_dtype = c_dtype; p.act = act; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
   p.a_group = 0; p.b_group = 0; p.a_gstride = 0; p.b_gstride = 0; p.a_total = (long)K * lda; p.b_total = (long)K * ldb;
-  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = colsum_acc;
+  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = colsum_acc; p.colsum_nparts = 2 * pl.splits; p.ones_col = -1;
   if (colsum_out && !(pl.bm == 512 && pl.tiles_n == 4 && pl.splits > 1)) return MVAE_ERR_UNSUPPORTED;
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * (N + (colsum_out ? 2 : 0)) * sizeof(float);
@@ -612,6 +614,8 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
         else { if (m0 + c4 < p.M) va.x = pa[0]; if (m0 + c4 + 1 < p.M) va.y = pa[1]; if (m0 + c4 + 2 < p.M) va.z = pa[2]; }
         if (b_vec) vb = *reinterpret_cast<const float4*>(pb);
         else { if (n0 + c4 < p.N) vb.x = pb[0]; if (n0 + c4 + 1 < p.N) vb.y = pb[1]; if (n0 + c4 + 2 < p.N) vb.z = pb[2]; }
+        const int od = p.ones_col - (n0 + c4);                // the virtual ones column (column sums of A), if it falls into this chunk
+        if (od == 0) vb.x = 1.f; else if (od == 1) vb.y = 1.f; else if (od == 2) vb.z = 1.f; else if (od == 3) vb.w = 1.f;
       }
       ra[i] = va; rb[i] = vb;
       row_step(p.a_group, p.a_gstride, p.lda, oa[i], ia[i]);
@@ -690,13 +694,16 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 32 + j * 16 + lr;
-      if (col >= p.N) continue;
+      if (col >= p.N && col != p.ones_col) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * 32 + i * 16 + lq * 4 + r;
         if (row >= p.M) continue;
         const float v = acc[i][j][r];
-        if (p.splits > 1) p.partial[((long)split * p.M + row) * p.N + col] = v;
+        if (col == p.ones_col) {                              // column sums of A
+          if (p.splits > 1) p.colsum_partial[(long)split * p.M + row] = v;
+          else p.colsum_out[row] = p.colsum_acc ? p.colsum_out[row] + v : v;
+        } else if (p.splits > 1) p.partial[((long)split * p.M + row) * p.N + col] = v;
         else store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
       }
     }
@@ -725,31 +732,35 @@ Plan make_plan_tn_f32(int M, int N, int R) {
 }
 }  // namespace
 
-size_t gemm_tn_f32_workspace_bytes(int M, int N, int R) {
-  Plan pl = make_plan_tn_f32(M, N, R);
-  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+size_t gemm_tn_f32_workspace_bytes(int M, int N, int R) {     // sized for the column-sum form too (one more B column, one partial per split)
+  Plan pl = make_plan_tn_f32(M, N + 1, R);
+  Plan p0 = make_plan_tn_f32(M, N, R);
+  const int sp = pl.splits > p0.splits ? pl.splits : p0.splits;
+  return sp > 1 ? (size_t)sp * M * (N + 1) * sizeof(float) : 0;
 }
 
 // A: rows of M floats, B: rows of N floats; group == 0 -> plain row-major [R][ld].  Row starts must be 16-byte aligned
 // (ld, gstride multiples of 4, bases 16-byte aligned) -- checked here.
 int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_group, long a_gstride, const float* B, long ldb, int b_group,
-                       long b_gstride, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool x3) {
+                       long b_gstride, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool x3,
+                       float* colsum_out, int colsum_acc) {
   if (M <= 0 || N <= 0) return MVAE_OK;
   if (R < 0 || !A || !B || !C) return MVAE_ERR_INVALID;
   if ((lda | ldb | a_gstride | b_gstride) & 3) return MVAE_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return MVAE_ERR_INVALID;
-  Plan pl = make_plan_tn_f32(M, N, R);
+  Plan pl = make_plan_tn_f32(M, colsum_out ? N + 1 : N, R);
   GemmArgs p;
   p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.partial = nullptr;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = R;
   p.c_dtype = MVAE_F32; p.act = MVAE_ACT_NONE; p.accumulate = accumulate;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
   p.a_group = a_group; p.a_gstride = a_gstride; p.b_group = b_group; p.b_gstride = b_gstride; p.a_total = 0; p.b_total = 0;
-  p.colsum_out = nullptr; p.colsum_partial = nullptr; p.colsum_acc = 0;
+  p.colsum_out = colsum_out; p.colsum_partial = nullptr; p.colsum_acc = colsum_acc; p.colsum_nparts = pl.splits; p.ones_col = colsum_out ? N : -1;
   if (pl.splits > 1) {
-    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    const size_t need = (size_t)pl.splits * M * (N + (colsum_out ? 1 : 0)) * sizeof(float);
     if (!ws || ws_bytes < need) return MVAE_ERR_WORKSPACE;
     p.partial = reinterpret_cast<float*>(ws);
+    if (colsum_out) p.colsum_partial = p.partial + (size_t)pl.splits * M * N;
   }
   if (x3) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);

@@ -12,7 +12,8 @@ int launch_gemm_nt_grouped(int dtype, int M, int N, int K, const void* A, long l
                            void* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn_f32_workspace_bytes(int M, int N, int R);
 int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_group, long a_gstride, const float* B, long ldb, int b_group,
-                       long b_gstride, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool x3 = false);
+                       long b_gstride, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool x3 = false,
+                       float* colsum_out = nullptr, int colsum_acc = 0);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
 int launch_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype,
                         const float* bias, int act, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);

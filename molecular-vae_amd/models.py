@@ -268,9 +268,10 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
         x = hs[l].view(TB, ldh)
         if Lq > 1:
             ops.gemm_tn(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldg, ldb=ldh)
-        if l > 0:
-            ops.gemm_tn(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
-        ops.colsum(a, TB, G4, grads[f"{prefix}.bias_ih_l{l}"], ldx=ldg)
+        if l > 0:              # the bias gradient (column sums of dG over all T*B rows) rides along this GEMM as its virtual ones column
+            ops.gemm_tn_f32_colsum(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], grads[f"{prefix}.bias_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
+        else:
+            ops.colsum(a, TB, G4, grads[f"{prefix}.bias_ih_l{l}"], ldx=ldg)
         grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
 
 
@@ -485,11 +486,10 @@ class _EncoderFn(torch.autograd.Function):
         mulv, d = W("mulv", (B, 2 * o)), W("d", (B, 512))
         dmulv = W("dmulv", (B, 2 * o))
         ops.lambda_bwd(mulv, eps, dz, dmu, dlogv, dmulv, B, o)
-        dWml = W("dWml", (2 * o, 512)); dbml = W("dbml", (2 * o,))
-        ops.gemm_tn(dmulv, d, dWml, 2 * o, 512, B)               # dW = dy^T . x straight from the batch-major operands (exact-f32 TN kernel)
-        ops.colsum(dmulv, B, 2 * o, dbml)
-        grads["lmbd.z_mean.weight"].copy_(dWml[:o]); grads["lmbd.z_log_var.weight"].copy_(dWml[o:])
-        grads["lmbd.z_mean.bias"].copy_(dbml[:o]); grads["lmbd.z_log_var.bias"].copy_(dbml[o:])
+        # dW = dy^T . x straight from the batch-major operands (exact-f32 TN kernel), db = column sums of dy as the GEMM's virtual ones column;
+        # one GEMM per head (the column halves of dmulv), written into the parameters' own gradient slots
+        for k, nm in enumerate(("lmbd.z_mean", "lmbd.z_log_var")):
+            ops.gemm_tn_f32_colsum(dmulv[:, k * o:(k + 1) * o], d, grads[nm + ".weight"], grads[nm + ".bias"], o, 512, B, lda=2 * o, ldb=512)
         dd = W("dd", (B, 512))
         ops.gemm_nt(dmulv, P["WmlT"], dd, B, 512, 2 * o, ldb=P["WmlT"].stride(0))
         ops.selu_bwd(dd, d)
@@ -497,8 +497,7 @@ class _EncoderFn(torch.autograd.Function):
         d1 = mod.dense_1[0]
         F = d1.in_features
         flat = W("flat", (B, F))
-        ops.gemm_tn(dd, flat, grads["dense_1.0.weight"], 512, F, B)
-        ops.colsum(dd, B, 512, grads["dense_1.0.bias"])
+        ops.gemm_tn_f32_colsum(dd, flat, grads["dense_1.0.weight"], grads["dense_1.0.bias"], 512, F, B)
         dflat = W("dflat", (B, F))
         ops.gemm_nt(dd, P["W1T"], dflat, B, F, 512)
         fork.run_deferred(0)      # the decoder's upper-layer weight-gradient GEMMs: from here on our own launches are chip-filling too
@@ -772,8 +771,13 @@ class _DecoderFn(torch.autograd.Function):
             side = mod._side_stream(dev)
             gflat.record_stream(side)
             fstate = peer.__dict__["_fork"]                               # the model's own fork state (ops.ForkState), kept by the peer
-            for k in range(len(parts)):                                   # first half: released by the peer after its head section; the rest
-                fstate.park(side, (lambda kk=k: weight_grads(kk)), 0 if 2 * k < len(parts) else 1)   # next to its row-resident LSTM backward
+            # first half of the parts: released by the peer after its head section; the rest next to its row-resident LSTM backward.  At small
+            # per-GPU batches (K = T * B short: a group of GEMMs is a few hundred microseconds) EVERYTHING waits for that second point: released
+            # earlier, the chip-filling 256 x 256 tiles only starve the peer's conv / dense backward (a 5 us bias column sum sat 308 us behind
+            # them at b = 128), while next to the 32-workgroup row-resident kernel (0.7 ms) they are hidden completely.
+            late_all = TB <= int(os.environ.get("MVAE_WGRAD_LATE_TB", 16384))      # measured: b = 128 8.38 -> 8.22 ms / step; B = 256: +0.13
+            for k in range(len(parts)):
+                fstate.park(side, (lambda kk=k: weight_grads(kk)), 1 if (late_all or 2 * k >= len(parts)) else 0)
         else:
             weight_grads(None)
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]
@@ -785,8 +789,7 @@ class _DecoderFn(torch.autograd.Function):
         ops.gemm_nt(dgx0, P["Wih0T"], dli, B, o, G4)
         # K6 backward
         ops.selu_bwd(dli, li)
-        ops.gemm_tn(dli, z, grads["latent_input.0.weight"], o, o, B)
-        ops.colsum(dli, B, o, grads["latent_input.0.bias"])
+        ops.gemm_tn_f32_colsum(dli, z, grads["latent_input.0.weight"], grads["latent_input.0.bias"], o, o, B)
         dz = torch.empty(B, o, dtype=f32, device=dev)
         ops.gemm_nt(dli, P["WliT"], dz, B, o, o, ldb=P["WliT"].stride(0))
         if fork:

@@ -355,10 +355,9 @@ class _MosesFn(torch.autograd.Function):
         ldh_e, ldh_d = Hq + _LDPAD, Hd + _LDPAD
 
         def lin_bwd(tag, dy, x, WT, wname, bname, M_in, N_out, need_dx=True):
-            """y = x W^T + b:  dW = dy^T x (exact-f32 TN kernel straight from the batch-major operands), db = colsum(dy), dx = dy W (via the
-            packed transpose WT [in, out])."""
-            ops.gemm_tn(dy, x, grads[wname], N_out, M_in, B, lda=dy.stride(0), ldb=x.stride(0))
-            ops.colsum(dy, B, N_out, grads[bname])
+            """y = x W^T + b:  dW = dy^T x (exact-f32 TN kernel straight from the batch-major operands) with db = colsum(dy) as its virtual
+            ones column, dx = dy W (via the packed transpose WT [in, out])."""
+            ops.gemm_tn_f32_colsum(dy, x, grads[wname], grads[bname], N_out, M_in, B, lda=dy.stride(0), ldb=x.stride(0))
             if not need_dx:
                 return None
             dx = W(tag + "_dx", (B, M_in))

@@ -143,6 +143,20 @@ def gemm_tn(A, B, out, M, N, K, lda=None, ldb=None, ldc=None, bias=None, act=L.A
     return out
 
 
+def gemm_tn_f32_colsum(A, B, out, colsum_out, M, N, K, lda=None, ldb=None, ldc=None, accumulate=False, colsum_accumulate=False):
+    """fp32: out[M,N] (+)= A[:K,:M]^T . B[:K,:N]  and  colsum_out[m] (+)= sum_k A[k,m]  in ONE launch (the bias gradient as a virtual ones column)."""
+    lib = L.load()
+    assert A.dtype == B.dtype == torch.float32
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    ldc = out.stride(0) if ldc is None else ldc
+    need = lib.mvae_gemm_tn_workspace(M, N, K, L.MVAE_F32)
+    ws = Scratch.get(need, A.device) if need else None
+    check(lib.mvae_gemm_tn_f32_colsum(M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, 1 if accumulate else 0, ptr(colsum_out),
+                                      1 if colsum_accumulate else 0, ptr(ws), need, stream_ptr()), "mvae_gemm_tn_f32_colsum")
+    return out
+
+
 def gemm_tn_colsum_supported(A, M, N, K):
     return A.dtype == torch.bfloat16 and bool(L.load().mvae_gemm_tn_colsum_supported(M, N, K))
 

@@ -349,3 +349,24 @@ def test_single_launch_loss_is_deterministic_and_resets_its_ticket():
             kl = -0.5 * torch.mean(1. + mu.double() - lv.double() ** 2 - torch.exp(mu.double()))
             assert abs(float(outs[0][1]) - float(xent)) < 2e-6 * abs(float(xent)) and abs(float(outs[0][2]) - float(kl)) < 2e-6 * abs(float(kl))
             assert abs(float(outs[0][0]) - float(xent + kl)) < 2e-6 * abs(float(xent + kl))
+
+
+@pytest.mark.parametrize("shape", [(288, 72, 15360), (512, 1344, 128), (584, 512, 1024), (120, 2304, 5000), (64, 64, 40), (5, 3, 7), (300, 130, 100000)])
+def test_f32_tn_gemm_with_the_bias_column_sum_as_a_virtual_ones_column(shape):
+    """mvae_gemm_tn_f32_colsum: C = A^T . B and colsum[m] = sum_k A[k, m] from one launch (B gets a column of ones at index N): shapes with
+    and without slack in the last 64-wide tile, with and without split-K, accumulate on both outputs, a column-slice A operand."""
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = torch.randn(K, 2 * M, device=dev, generator=g)[:, M // 4 * 4:M // 4 * 4 + M] if M % 4 == 0 else torch.randn(K, (M + 3) // 4 * 4, device=dev, generator=g)
+    lda = A.stride(0)
+    Bm = torch.randn(K, (N + 3) // 4 * 4, device=dev, generator=g)
+    Cw = torch.full((M, N), float("nan"), device=dev); cs = torch.full((M,), float("nan"), device=dev)
+    ops.gemm_tn_f32_colsum(A, Bm, Cw, cs, M, N, K, lda=lda, ldb=Bm.stride(0))
+    ref = A[:, :M].double().t() @ Bm[:, :N].double(); rcs = A[:, :M].double().sum(0)
+    scale = float(ref.abs().max())
+    assert float((Cw.double() - ref).abs().max()) < 2e-5 * scale and float((cs.double() - rcs).abs().max()) < 2e-5 * float(rcs.abs().max() + 1)
+    ops.gemm_tn_f32_colsum(A, Bm, Cw, cs, M, N, K, lda=lda, ldb=Bm.stride(0), accumulate=True, colsum_accumulate=True)
+    assert float((Cw.double() - 2 * ref).abs().max()) < 4e-5 * scale and float((cs.double() - 2 * rcs).abs().max()) < 4e-5 * float(rcs.abs().max() + 1)
+    plain = torch.empty(M, N, device=dev)
+    ops.gemm_tn(A, Bm, plain, M, N, K, lda=lda, ldb=Bm.stride(0))
+    assert float((plain.double() - ref).abs().max()) < 2e-5 * scale

@@ -85,7 +85,7 @@ def test_forward_backward_bookkeeping_with_stubbed_kernels(monkeypatch):
         def f(*a, **k):
             calls.append(name)
         return f
-    for name in ("gemm_nt", "gemm_tn", "colsum_t", "cast_transpose", "permute021", "gather_rows_tb", "scatter_rows_tb", "rowsum", "timesum", "colsum",
+    for name in ("gemm_nt", "gemm_tn", "gemm_tn_f32_colsum", "colsum_t", "cast_transpose", "permute021", "gather_rows_tb", "scatter_rows_tb", "rowsum", "timesum", "colsum",
                  "selu_bwd", "conv1d_pack_weights", "conv1d_selu_fwd", "conv1d_selu_bwd", "lambda_fwd", "lambda_bwd", "softmax_tb_fwd", "softmax_tb_bwd",
                  "rnn_fwd", "rnn_bwd"):
         monkeypatch.setattr(ops, name, stub(name))
