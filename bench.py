@@ -21,6 +21,7 @@ Extra objects on the line:
   secondary    -- N = 1 only: the same step at configs[1] (B=512 bf16), at the per-rank shape of configs[2] (b=128 bf16, with its own
                   roofline object), in the exact-f32 parity mode (B=1024), the mosesvae.VAE step of configs[3] (B=1024) and the long-sequence
                   stress of configs[4] (L=256, C=64, B=2048, with the GB/s of its HBM-bound kernels), each on fewer steps.
+  input_pipeline -- N = 1: the main workload's step fed through DeviceDataset.batches (250k-molecule corpus in HBM) instead of one resident batch.
   comm         -- N > 1 only: allreduce_exposed_ms (HIP-event time the main stream waited for the gradient all-reduce in the optimiser
                   step), the world size and backend torch.distributed reported, gradient bytes per step.
 `--model moses` / `--model models2d` bench the mosesvae.VAE path (configs[3]) and the models2d.VAE variant the same way.
@@ -156,6 +157,24 @@ class MolVaeWorkload:
     def flops_per_step(self):
         return flops_per_molecule(self.L, self.C) * self.B
 
+    def pipeline_steps(self, steps, warmup, n_corpus=250000):
+        """The same step fed THROUGH the device-side input pipeline: a 250k-molecule uint8 corpus resident in HBM (30 MB),
+        per-epoch shuffle, mvae_expand_indices to the (idx, ohe) pair of data_loader.py:26-31 -- instead of one resident batch.  ms / step."""
+        import torch
+        from molecular_vae_amd import data as D
+        g = torch.Generator().manual_seed(99)
+        store = torch.randint(0, self.C, (n_corpus, self.L), generator=g, dtype=torch.uint8).numpy()
+        ds = D.DeviceDataset(store, self.C, self.data.device)
+        it = ds.batches(self.B, epoch=1, seed=0)
+        for _ in range(warmup):
+            d, o = next(it); self.mv.train_step(self.model, self.optimizer, self.loss_function, d, o)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            d, o = next(it); self.mv.train_step(self.model, self.optimizer, self.loss_function, d, o)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
     def hbm_kernels(self, tag_ms):
         """HBM-bound kernels of the step: algorithmic bytes = one read + one write of their operands; achieved GB/s from
         the HIP-event time of the launches (BASELINE configs[4] asks for these against the 8 TB/s roof)."""
@@ -230,7 +249,7 @@ def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB):
     return Models2dWorkload(B, dtype, dev, rank, sync)
 
 
-def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_SEQ, C=VOCAB):
+def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_SEQ, C=VOCAB, pipeline=False):
     """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
     import torch
     import torch.distributed as dist
@@ -243,6 +262,11 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
             torch.cuda.synchronize()
             log(f"[{label}] first step done, loss={float(loss):.5f}")
     torch.cuda.synchronize()
+    # a full Python garbage collection NOW, outside the timed region: the previous configurations of this process leave a large heap
+    # behind, and a generation-2 pass landing inside the 20 timed steps showed up as +3 ms per step on the b = 128 line (identical device
+    # phase times, host stalled)
+    import gc
+    gc.collect()
     if world > 1:
         dist.barrier()
     ops.PROFILE = {}
@@ -277,10 +301,48 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
     roof["whole_step_tflops"] = round(wl.flops_per_step() * steps / dt / 1e12, 2)
     res = dict(value=round(B * world * steps / dt, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup, dtype=dtype,
                final_loss=round(float(loss), 6), roofline=roof, config=wl.config(world), comm=comm)
+    if pipeline and hasattr(wl, "pipeline_steps"):
+        pms = wl.pipeline_steps(max(5, steps // 2), 2)
+        res["input_pipeline"] = dict(ms_per_step=round(pms, 3), value=round(B * world / (pms * 1e-3), 1), unit="molecules/s",
+                                     overhead_vs_resident_batch=round(pms / ms - 1.0, 4),
+                                     what="same step, batches drawn from a 250k-molecule uint8 corpus resident in HBM (DeviceDataset.batches: "
+                                          "per-epoch shuffle + mvae_expand_indices to (idx, one-hot))")
+        log(f"[{label}] through the input pipeline: {pms:.2f} ms/step")
     del wl
     ops.release_caches()
     torch.cuda.empty_cache()
     return res
+
+
+def measure_generation(dev, b_size=2000, reps=5):
+    """train_sample.py:29-45 / hugesample.py:94-95 ("Samples per second"): latents -> MolDecoder (forward-only pass, nothing saved for backward)
+    -> arg-max -> strings through the charset, batches of 2000 as the reference draws them.  Random-init weights; samples/s incl. the host
+    side string assembly, and the device part alone."""
+    import torch
+    import molecular_vae_amd as mv
+    from molecular_vae_amd import ops
+    torch.manual_seed(42)
+    model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB).to(dev).eval()
+    charset = {i: ch for i, ch in enumerate(" #()+-123=@BCFHNOS[]clnors"[:VOCAB].ljust(VOCAB, "x"))}
+    mv.generate_from_latent(model, charset, n=b_size, batch_size=b_size)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        strings, _ = mv.generate_from_latent(model, charset, n=b_size, batch_size=b_size)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    z = torch.rand(b_size, LATENT, device=dev)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        model.decoder(z); s.record()
+        for _ in range(reps):
+            model.decoder(z).argmax(dim=2)
+        e.record(); torch.cuda.synchronize()
+    dev_ms = s.elapsed_time(e) / reps
+    del model
+    ops.release_caches(); torch.cuda.empty_cache()
+    return dict(value=round(b_size / dt, 1), unit="samples/s", batch=b_size, device_only_samples_per_s=round(b_size / (dev_ms * 1e-3), 1),
+                device_ms_per_batch=round(dev_ms, 3), what="MolDecoder from uniform latents, arg-max, charset strings (train_sample.py:29-45)")
 
 
 def main():
@@ -322,7 +384,8 @@ def main():
             die(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
         B, scaling = args.global_batch // world, "strong"
 
-    main_res = measure(args.model, B, args.dtype, args.steps, args.warmup, dev, rank, world, sync, "main", args.seq_len, args.vocab)
+    main_res = measure(args.model, B, args.dtype, args.steps, args.warmup, dev, rank, world, sync, "main", args.seq_len, args.vocab,
+                       pipeline=(world == 1 and args.model == "molvae" and not args.no_secondary))
     metric = {"molvae": "molecules/s (ELBO fwd+bwd+step)", "moses": "molecules/s (mosesvae.VAE KL+CE fwd+bwd+step)",
               "models2d": "molecules/s (models2d.VAE ELBO fwd+bwd+step)"}[args.model]
     cfg = main_res["config"]; cfg["final_loss"] = main_res["final_loss"]
@@ -331,6 +394,8 @@ def main():
                data="synthetic", config=cfg, roofline=main_res["roofline"])
     if main_res.get("comm") is not None:
         out["comm"] = main_res["comm"]
+    if main_res.get("input_pipeline") is not None:
+        out["input_pipeline"] = main_res["input_pipeline"]
 
     if (world == 1 and args.model == "molvae" and not args.no_secondary and args.batch == 0 and args.dtype == "bf16"
             and (args.seq_len, args.vocab) == (L_SEQ, VOCAB)):
@@ -345,6 +410,7 @@ def main():
             r = measure(mdl, b, dt_, st, wu, dev, rank, 1, None, label, Lq, Cq)
             sec[label] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=st, warmup=wu, dtype=dt_,
                               per_gpu_batch=b, final_loss=r["final_loss"], roofline=r["roofline"], workload=r["config"]["workload"])
+        sec["generation_from_latent_b2000"] = measure_generation(dev)
         out["secondary"] = sec
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

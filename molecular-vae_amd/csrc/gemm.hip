@@ -565,7 +565,9 @@ constexpr int TNF_BM = 64, TNF_KS = 32, TNF_LD = 80;
 // X3: the products go to the bf16 MFMA as hi.hi + hi.lo + lo.hi (split_x3 in tile_pipe.hpp).  The 16x16x32 fragment of lane l is eight k-values
 // of column (l & 15) for k-slice (l >> 4); WHICH eight is free as long as A and B agree, so slice f takes rows f, f + 4, ..., f + 28 of the
 // stage -- exactly the eight values the fp32 form already reads for its eight 16x16x4 MFMAs.  12 bf16 MFMAs per stage instead of 32 fp32 ones.
-template <bool X3>
+// CS: instantiation that can produce the column sums of A through a virtual ones column of B (p.ones_col); the plain instantiation carries no
+// trace of it -- this loop has no VALU slack (four compares and selects per staged chunk cost the f32 decoder's weight gradients +28 %).
+template <bool X3, bool CS = false>
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
   __shared__ float As[2][TNF_KS * TNF_LD];
   __shared__ float Bs[2][TNF_KS * TNF_LD];
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
   // each thread stages 2 float4 of A and 2 of B per stage: r-row = id >> 4, column chunk = id & 15 (id = tid, tid + 256)
   const int c4 = (tid & 15) * 4;
   const bool a_vec = (m0 + c4 + 3 < p.M), b_vec = (n0 + c4 + 3 < p.N);     // whole chunk inside the matrix (host checked alignment)
+  const bool ones_here = CS && p.ones_col >= n0 && p.ones_col < n0 + TNF_BM;
   float4 ra[2], rb[2];
   // per-thread row offsets, kept incrementally: a runtime integer division per row and stage (grouped operands) costs as many issue
   // cycles as the stage's MFMAs
@@ -614,8 +617,12 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
         else { if (m0 + c4 < p.M) va.x = pa[0]; if (m0 + c4 + 1 < p.M) va.y = pa[1]; if (m0 + c4 + 2 < p.M) va.z = pa[2]; }
         if (b_vec) vb = *reinterpret_cast<const float4*>(pb);
         else { if (n0 + c4 < p.N) vb.x = pb[0]; if (n0 + c4 + 1 < p.N) vb.y = pb[1]; if (n0 + c4 + 2 < p.N) vb.z = pb[2]; }
-        const int od = p.ones_col - (n0 + c4);                // the virtual ones column (column sums of A), if it falls into this chunk
-        if (od == 0) vb.x = 1.f; else if (od == 1) vb.y = 1.f; else if (od == 2) vb.z = 1.f; else if (od == 3) vb.w = 1.f;
+        if constexpr (CS) {
+          if (ones_here) {                                    // workgroup-uniform: only the tile column that holds the virtual ones column
+            const int od = p.ones_col - (n0 + c4);
+            if (od == 0) vb.x = 1.f; else if (od == 1) vb.y = 1.f; else if (od == 2) vb.z = 1.f; else if (od == 3) vb.w = 1.f;
+          }
+        }
       }
       ra[i] = va; rb[i] = vb;
       row_step(p.a_group, p.a_gstride, p.lda, oa[i], ia[i]);
@@ -694,13 +701,13 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 32 + j * 16 + lr;
-      if (col >= p.N && col != p.ones_col) continue;
+      if (col >= p.N && !(CS && col == p.ones_col)) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * 32 + i * 16 + lq * 4 + r;
         if (row >= p.M) continue;
         const float v = acc[i][j][r];
-        if (col == p.ones_col) {                              // column sums of A
+        if (CS && col == p.ones_col) {                        // column sums of A
           if (p.splits > 1) p.colsum_partial[(long)split * p.M + row] = v;
           else p.colsum_out[row] = p.colsum_acc ? p.colsum_out[row] + v : v;
         } else if (p.splits > 1) p.partial[((long)split * p.M + row) * p.N + col] = v;
@@ -762,8 +769,14 @@ int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_grou
     p.partial = reinterpret_cast<float*>(ws);
     if (colsum_out) p.colsum_partial = p.partial + (size_t)pl.splits * M * N;
   }
-  if (x3) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, dim3(pl.tiles_m * pl.tiles_n, pl.splits), dim3(256), 0, st, p);
+  const dim3 tgrid(pl.tiles_m * pl.tiles_n, pl.splits);
+  if (colsum_out) {
+    if (x3) hipLaunchKernelGGL((gemm_tn_f32_kernel<true, true>), tgrid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_f32_kernel<false, true>), tgrid, dim3(256), 0, st, p);
+  } else {
+    if (x3) hipLaunchKernelGGL((gemm_tn_f32_kernel<true, false>), tgrid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_f32_kernel<false, false>), tgrid, dim3(256), 0, st, p);
+  }
   MVAE_CHECK_HIP(hipGetLastError());
   if (pl.splits > 1) {
     long n = (long)M * N;

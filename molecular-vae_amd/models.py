@@ -268,9 +268,13 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
         x = hs[l].view(TB, ldh)
         if Lq > 1:
             ops.gemm_tn(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldg, ldb=ldh)
-        if l > 0:              # the bias gradient (column sums of dG over all T*B rows) rides along this GEMM as its virtual ones column
+        if l > 0 and H % 64:   # the bias gradient (column sums of dG over all T*B rows) rides along this GEMM as its virtual ones column, in the
+            # slack of the last 64-wide tile (H = 72).  Not when H is a whole number of tiles (the f32 decoder, H = 1024: a 17th tile column
+            # turns 4 full rounds of workgroups into 4.25 -- 12.4 -> 20.0 ms per GEMM, measured)
             ops.gemm_tn_f32_colsum(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], grads[f"{prefix}.bias_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
         else:
+            if l > 0:
+                ops.gemm_tn(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh)
             ops.colsum(a, TB, G4, grads[f"{prefix}.bias_ih_l{l}"], ldx=ldg)
         grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
 
@@ -565,9 +569,7 @@ class MolDecoder(nn.Module, _SavedState):
         self.overlap_weight_grads = True       # run the weight-gradient GEMMs on a side stream under the encoder's backward
 
     def _side_stream(self, dev):
-        if self.__dict__["_side"] is None:
-            self.__dict__["_side"] = torch.cuda.Stream(device=dev)     # (stream priorities were measured: no effect here)
-        return self.__dict__["_side"]
+        return ops.side_stream(dev)       # process-wide, probed not to share a hardware queue with the main stream (stream priorities: no effect)
 
     def forward(self, x):
         # under no_grad (evaluation, train.py:120-153 / sampling from a latent, train_sample.py:32) nothing is saved for backward

@@ -76,9 +76,7 @@ class VAE(nn.Module, _SavedState):
         self.__dict__["_side"] = None
 
     def _side_stream(self, dev):
-        if self.__dict__["_side"] is None:
-            self.__dict__["_side"] = torch.cuda.Stream(device=dev)
-        return self.__dict__["_side"]
+        return ops.side_stream(dev)
 
     @property
     def device(self):
