@@ -365,15 +365,19 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_fwd_kernel(StepArgsF
 // tile needs 64 KB of operands per 64-deep K-step for 8.4 MFLOP (128 FLOP/B, against 85 for the 128-row tile), which is what counts for
 // a loop bound by the per-CU L2 -> LDS intake.
 // Small batches (B <= 256) take the same kernel with 32-unit tiles (BMW = 128 weight rows, 256 threads = 4 waves along the batch rows).
-template <int BMW, int BNB, int NBUF, int MODE = 2>
-__global__ __launch_bounds__(BMW * 2) void lstm_step_fwd_gm_kernel(StepArgsF p) {
+// WS (32-unit tiles only): 512 threads, waves 4-7 only issue the LDS-DMA pieces (tile_gemm_ws).  The small-batch tile's K-step is 16
+// MFMAs per wave against 6 DMA pieces of 60-180 issue cycles each: with every wave doing both jobs the pieces, not the MFMAs, set the pace
+// (~950 cycles per K-step for 256 cycles of MFMA at b = 128).
+template <int BMW, int BNB, int NBUF, int MODE = 2, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : BMW * 2) void lstm_step_fwd_gm_kernel(StepArgsF p) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(BMW == 256 || BMW == 128, "weight rows per tile: 64 or 32 units x 4 gates");
+  static_assert(!WS || BMW == 128, "loader / consumer split: the 4-wave tile only");
   constexpr int NT = BMW * 2;                   // 8 waves as 2 (weight rows) x 4 (batch rows), or 4 waves as 1 x 4
   constexpr int BU = BMW / 4;                   // hidden units per tile
   constexpr int MI = 8, NI = BNB / 64;          // wave tile: 128 weight rows x (BNB / 4) batch rows
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WS ? ((tid >> 6) & 3) : (tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int per_task = p.tiles_m * p.tiles_j;
   const int bid = xcd_remap_r(blockIdx.x, p.ntask * per_task);
   const int task = bid / per_task;
@@ -445,18 +449,20 @@ __global__ __launch_bounds__(BMW * 2) void lstm_step_fwd_gm_kernel(StepArgsF p) 
       const uint32_t lda = (uint32_t)q.lda0 * 2u, ldw = (uint32_t)q.ldw0 * 2u;
       auto offW = [&](int r) -> uint32_t { return (uint32_t)wrow(r) * ldw; };
       auto offX = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < B ? (uint32_t)gn * lda : PIPE_OOB; };
-      pipe_seg_init<T, BMW, BNB, NT>(s0, q.W0, (uint32_t)(4 * H) * ldw, q.A0, (uint32_t)B * lda, offW, offX, q.K0, tid);
+      pipe_seg_init<T, BMW, BNB, NT>(s0, q.W0, (uint32_t)(4 * H) * ldw, q.A0, (uint32_t)B * lda, offW, offX, q.K0, WS ? (tid & 255) : tid);
       if (q.A0 == nullptr) s0.nk = 0;
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * 2u, ldw = (uint32_t)q.ldw1 * 2u;
       auto offW = [&](int r) -> uint32_t { return (uint32_t)wrow(r) * ldw; };
       auto offX = [&](int r) -> uint32_t { const int gn = n0 + r; return gn < B ? (uint32_t)gn * lda : PIPE_OOB; };
-      pipe_seg_init<T, BMW, BNB, NT>(s1, q.W1, (uint32_t)(4 * H) * ldw, q.A1, (uint32_t)B * lda, offW, offX, q.K1, tid);
+      pipe_seg_init<T, BMW, BNB, NT>(s1, q.W1, (uint32_t)(4 * H) * ldw, q.A1, (uint32_t)B * lda, offW, offX, q.K1, WS ? (tid & 255) : tid);
       if (q.A1 == nullptr) s1.nk = 0;
     }
-    tile_gemm_pipe_all<T, BMW, BNB, MI, NI, NBUF, NT, MODE>(smem, s0, s1, wm * 128, wn * (16 * NI), acc, tid);
+    if constexpr (WS) tile_gemm_ws<T, BMW, BNB, MI, NI, NBUF, NI, 0>(smem, s0, s1, 0, wn * (16 * NI), acc, tid);
+    else tile_gemm_pipe_all<T, BMW, BNB, MI, NI, NBUF, NT, MODE>(smem, s0, s1, wm * 128, wn * (16 * NI), acc, tid);
   }
+  if constexpr (WS) { if (tid >= 256) return; }          // loader waves own no accumulators
 #ifdef MVAE_TUNING
   if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.c_out[0] = 1.f; return; }
 #endif
@@ -1297,7 +1303,11 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       }
       else if (BMW == 256) { lds = 3 * (256 + 128) * KB; MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<256, 128, 3>)); }
       else if (BNB == 128) { lds = 4 * (128 + 128) * KB; MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<128, 128, 4>)); }
-      else { lds = 4 * (128 + 64) * KB; MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<128, 64, 4>)); }
+      else {
+        lds = 4 * (128 + 64) * KB;
+        if (tune_int("MVAE_FWD_GM_WS", 1)) { block = dim3(512); MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<128, 64, 4, 2, true>)); }
+        else MVAE_STEP_LAUNCH((lstm_step_fwd_gm_kernel<128, 64, 4>));
+      }
       continue;
     }
 #define FWD_CASE(TT_, BM_, NB_) if (BJ == 32 && BM == BM_ && nbuf == NB_) { MVAE_STEP_LAUNCH((lstm_step_fwd_kernel<TT_, BM_, 32, NB_>)); continue; }
