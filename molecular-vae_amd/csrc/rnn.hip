@@ -859,17 +859,24 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
     static_assert(BM % RPI == 0, "whole row groups per thread");
     // host guarantees (rnn_bwd_impl, big_fused): B % BM == 0, H % BN == 0, 16-byte aligned everything -- every group is whole and in range
     PipeSeg<BM, BN> s0, s1;
+#ifdef MVAE_TUNING
+    // diagnostic build, MVAE_DBG bit 2: every workgroup contracts the SAME operand panels (tile 0 of its cell's matrices): all L2 hits after the
+    // first touch -- separates the fabric (L2-miss) share of the main loop from the rest.  Results wrong.
+    const int am0 = (p.dbg & 4) ? 0 : m0, an0 = (p.dbg & 4) ? 0 : n0;
+#else
+    const int am0 = m0, an0 = n0;
+#endif
     {
       const uint32_t lda = (uint32_t)q.lda0 * 2u, ldw = (uint32_t)q.ldw0 * 2u;
-      auto offA = [&](int r) -> uint32_t { return (uint32_t)(m0 + r) * lda; };
-      auto offB = [&](int r) -> uint32_t { return (uint32_t)(n0 + r) * ldw; };
+      auto offA = [&](int r) -> uint32_t { return (uint32_t)(am0 + r) * lda; };
+      auto offB = [&](int r) -> uint32_t { return (uint32_t)(an0 + r) * ldw; };
       pipe_seg_init<T, BM, BN>(s0, q.A0, (uint32_t)B * lda, q.W0, (uint32_t)H * ldw, offA, offB, p.gru3 ? 3 * H : q.K0, tid & 255);
       if (p.gru3) { s0.hole_st = (int)(2 * H * 2 / KB); s0.hole_bytes = (uint32_t)H * 2u; }
     }
     {
       const uint32_t lda = (uint32_t)q.lda1 * 2u, ldw = (uint32_t)q.ldw1 * 2u;
-      auto offA = [&](int r) -> uint32_t { return (uint32_t)(m0 + r) * lda; };
-      auto offB = [&](int r) -> uint32_t { return (uint32_t)(n0 + r) * ldw; };
+      auto offA = [&](int r) -> uint32_t { return (uint32_t)(am0 + r) * lda; };
+      auto offB = [&](int r) -> uint32_t { return (uint32_t)(an0 + r) * ldw; };
       pipe_seg_init<T, BM, BN>(s1, q.A1, (uint32_t)B * lda, q.W1, (uint32_t)H * ldw, offA, offB, (p.gru3 && !q.seg1_full) ? 3 * H : q.K1, tid & 255);
     }
     const int nk = s0.nk + s1.nk;
