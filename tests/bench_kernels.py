@@ -62,8 +62,19 @@ def timeit(fn, n=5):
     return s.elapsed_time(e) / n
 
 
+def host_us(fn, launches):
+    """Host time to ENQUEUE one pass on an idle GPU (no wait inside), us per launch."""
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); fn(); t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    return 1e6 * (t1 - t0) / launches
+
+
 nl = T + NL - 1
 per_t = 2 * B * G4 * (H + 3 * 2 * H)
+if "host" in which:
+    print(f"host enqueue: fwd {host_us(fwd, nl):.2f} us/launch, bwd {host_us(bwd, nl):.2f} us/launch (bwd split forms: two launches per diagonal)")
 if "fwd" in which:
     ms = timeit(fwd)
     print(f"fwd : {ms:.3f} ms  {1e3 * ms / nl:.1f} us/launch  {per_t * T / ms / 1e9:.1f} TFLOP/s")
