@@ -9,7 +9,7 @@ import weakref
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MVAE_LIB: absolute path of a diagnostic build (csrc/build.sh tune -> libmvae_hip_tune.so) for timing decompositions; bench.py refuses to
+# MVAE_LIB: absolute path of a diagnostic build (csrc/build.sh tune -> tests/tuning/lib/libmvae_hip_tune.so: outside the package, never next to the product library) for timing decompositions; bench.py refuses to
 # run with any MVAE_* variable set, so a measured number always comes from the product library.
 LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
 

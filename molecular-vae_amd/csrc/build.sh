@@ -8,15 +8,15 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 if [ "${1:-}" = "tune" ]; then
-  mkdir -p build/tune
+  mkdir -p build/tune ../../tests/tuning/lib
   pids=()
   for f in gemm rnn rnn_rowres elementwise conv capi; do
     $HIPCC $FLAGS -DMVAE_TUNING -c $f.hip -o build/tune/$f.o &
     pids+=($!)
   done
   for p in "${pids[@]}"; do wait $p; done
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmvae_hip_tune.so build/tune/gemm.o build/tune/rnn.o build/tune/rnn_rowres.o build/tune/elementwise.o build/tune/conv.o build/tune/capi.o
-  echo "built $(cd .. && pwd)/libmvae_hip_tune.so"
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../../tests/tuning/lib/libmvae_hip_tune.so build/tune/gemm.o build/tune/rnn.o build/tune/rnn_rowres.o build/tune/elementwise.o build/tune/conv.o build/tune/capi.o
+  echo "built $(cd ../../tests/tuning/lib && pwd)/libmvae_hip_tune.so"
   exit 0
 fi
 pids=()

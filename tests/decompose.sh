@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/decomp.txt
 mkdir -p $ROOT/gpurun_out
 : > $OUT
-export MVAE_LIB=$ROOT/molecular-vae_amd/libmvae_hip_tune.so
+export MVAE_LIB=$ROOT/tests/tuning/lib/libmvae_hip_tune.so
 for B in ${1:-512}; do
   for dbg in 0 1 2; do
     echo "== B=$B MVAE_DBG=$dbg (0 = full kernel, 1 = main loop only, 2 = epilogue only)" >> $OUT

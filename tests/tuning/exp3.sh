@@ -10,5 +10,5 @@ for B in 1024 128; do
   for sp in 1 0 2 1284 644 1281; do r=$(MVAE_BWD_SPLIT=$sp python3 tests/bench_kernels.py 24 $B bwd 2>&1 | grep "bwd :"); echo "B=$B BWD_SPLIT=$sp $r"; done
   r=$(python3 tests/bench_kernels.py 24 $B fwd 2>&1 | grep "fwd :"); echo "B=$B $r"
 done
-export MVAE_LIB=$ROOT/molecular-vae_amd/libmvae_hip_tune.so
+export MVAE_LIB=$ROOT/tests/tuning/lib/libmvae_hip_tune.so
 for dbg in 0 1 2; do r=$(MVAE_DBG=$dbg python3 tests/bench_kernels.py 24 1024 fwd,bwd 2>&1 | grep "wd :" | tr '\n' ' '); echo "GRU B=1024 DBG=$dbg $r"; done

@@ -1,6 +1,6 @@
 #!/bin/bash
 ROOT=$(pwd)
-export MVAE_LIB=$ROOT/molecular-vae_amd/libmvae_hip_tune.so
+export MVAE_LIB=$ROOT/tests/tuning/lib/libmvae_hip_tune.so
 for rep in 1 2; do
 for mode in 0 1 2 3; do
   for dbg in 0 1; do

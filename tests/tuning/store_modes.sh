@@ -4,7 +4,7 @@
 #   10: + saved gates not stored (half the bytes);  0 / 4 / 8: the same three with the main loop in front.
 set -uo pipefail
 ROOT=$(pwd)
-export MVAE_LIB=$ROOT/molecular-vae_amd/libmvae_hip_tune.so
+export MVAE_LIB=$ROOT/tests/tuning/lib/libmvae_hip_tune.so
 for dbg in 0 4 8 2 6 10; do
   echo "== B=1024 MVAE_DBG=$dbg"
   MVAE_DBG=$dbg timeout -k 10 300 python3 tests/bench_kernels.py 24 1024 fwd 2>&1 | grep -v amdgpu.ids || exit 1
