@@ -562,7 +562,7 @@ struct StepTaskB {
   const uint8_t* dmask;               // [B, H] injected keep mask of this cell's OUTPUT (nullptr: hash)
   uint32_t didx0;
 };
-struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split, gru3; DropArgs drop; };
+struct StepArgsB { StepTaskB t[MVAE_MAX_LAYERS]; const int* lengths; float* partial; int ntask, B, H, tiles_m, tiles_n, dbg, vec, cell, split, gru3, tailpref; DropArgs drop; };
 
 // Gate-derivative math of one (batch row, 8 hidden units) group, given dh = sum of the two contractions (fp32): the general form (any n,
 // scalar or vector accesses, operands requested where they are used).  The element-wise launch of the split forms and ragged tiles use it.
@@ -903,17 +903,35 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
 #endif
     if (wv >= 4) {
       // ---- loader waves: every group's operands first (oldest in the memory queue), then the ring
+      // LSTM cells (a fixed number of operand loads per group): the loads go out BEHIND the last ring stage -- in front of the first they
+      // delayed the whole main loop by their HBM latency (6 us of the launch, tune build) -- and land under the last three K-steps
+      constexpr int NTAIL = NIT * (HAS_DY ? 10 : 8);
+      const bool tail_form = p.cell == MVAE_CELL_LSTM && nk >= NBUF && run_main && p.tailpref;
+      if (tail_form) {
+        tile_gemm_ws_loader_tail<T, BM, BN, NBUF, NTAIL>(smem, s0, s1, wv - 4, [&]() {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) bwd_raw_load<HAS_DY>(p, q, row0 + it * RPI, j8, raw[it]);
+        });
+        ws_barrier();
+      } else {
+#ifdef MVAE_TUNING
+      if (!(p.dbg & 64))                       // diagnostic build, MVAE_DBG bit 6: no operand prefetch (with bit 0: what the launch + barriers alone cost)
+#endif
 #pragma unroll
       for (int it = 0; it < NIT; ++it) bwd_raw_load<HAS_DY>(p, q, row0 + it * RPI, j8, raw[it]);
-      if (nk > 0 && run_main) { tile_gemm_ws_loader<T, BM, BN, NBUF>(smem, s0, s1, wv - 4); ws_barrier(); }
+      if (nk > 0 && run_main) { tile_gemm_ws_loader<T, BM, BN, NBUF>(smem, s0, s1, wv - 4, p.dbg); ws_barrier(); }
+      }
 #ifdef MVAE_TUNING
       if (p.dbg & 1) return;
 #endif
       __syncthreads();
       finish_all();
     } else {
+#ifdef MVAE_TUNING
+      if (!(p.dbg & 64))
+#endif
       bwd_raw_load<HAS_DY>(p, q, row0, j8, raw[0]);
-      if (nk > 0 && run_main) { tile_gemm_ws_consumer<T, BM, BN, MI, NI, NBUF, NI, 0>(smem, nk, wm * WM, wn * WN, acc, lane); ws_barrier(); }
+      if (nk > 0 && run_main) { tile_gemm_ws_consumer<T, BM, BN, MI, NI, NBUF, NI, 0, true>(smem, nk, wm * WM, wn * WN, acc, lane, p.dbg); ws_barrier(); }
 #ifdef MVAE_TUNING
       if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) q.dc_out[0] = 1.f; return; }
 #endif
@@ -989,7 +1007,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
       s0.nk = nk0; s1.nk = 0;
       tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
     } else {
-      if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
+      if constexpr (WS) tile_gemm_ws<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0, (BM * BN <= 128 * 128)>(smem, s0, s1, wm * WM, wn * WN, acc, tid);   // interleaved fragment reads (the 256 x 128 tile has no registers to spare for them)
       else tile_gemm_pipe<T, BM, BN, MI, NI, (NBUF > 0 ? NBUF : 3), NI, 0>(smem, s0, s1, wm * WM, wn * WN, acc, tid);
     }
   } else {
@@ -1437,6 +1455,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   a.drop.seed = d->drop_seed;
   // GRU: skip the zero gate-slot block of each contraction (k in [2H,3H) of dG . W_hh^T, k >= 3H of dG_up . W_ih^T); the skipped ranges
   // must start on whole K-steps (and the 4-way split's half of 3H as well)
+  a.tailpref = tune_int("MVAE_BWD_TAILPREF", 1);      // fused prefetching form: the loader waves' operand loads behind the last ring stage (A/B knob)
   a.gru3 = (gru && tune_int("MVAE_GRU3", 1) && H % ke == 0 && (nsplit != 4 || (3 * H / 2) % ke == 0)) ? 1 : 0;
   a.B = B; a.H = H; a.tiles_m = (B + BM - 1) / BM; a.tiles_n = (H + BN - 1) / BN; a.vec = vec ? 1 : 0;
 #ifdef MVAE_TUNING

@@ -595,28 +595,99 @@ __device__ __forceinline__ void tile_gemm_ws_tn(char* smem, const PipeSegTN<MI>&
   ws_barrier();
 }
 
+// One half K-step of a consumer wave with its fragment reads INTERLEAVED: MFMA m of the MI x NI block on fragments (a, b) is followed, for
+// m < MI + NI, by ONE ds_read_b128 of the next fragment set (na, nb).  A consumer wave issues in order: eight reads in a block cost their
+// LDS issue slots on top of the MFMA block (measured on the fused backward step, tune build: barriers alone 21.5 us per launch, + reads
+// 34.0, + MFMAs 49.5, both 63.6 -- purely additive); issued one per MFMA gap they sit under the matrix pipe's 16 cycles per instruction.
+// Order of the reads: a[0], b[0..NI-1], a[1..MI-1] -- what the next block's first MFMAs need comes first.
+// read r of a fragment set, in the order a[0], b[0..NI-1], a[1..MI-1]
+template <int MI, int NI, int JS, int BOUT, int R>
+__device__ __forceinline__ void ilv_read(u32x4 (&na)[MI], u32x4 (&nb)[NI], uint32_t a_addr, uint32_t b_addr) {
+  if constexpr (R == 0) na[0] = lds_read128<0>(a_addr);
+  else if constexpr (R <= NI) nb[R - 1] = lds_read128<(((R - 1) / JS) * BOUT + ((R - 1) % JS) * 16) * KB>(b_addr);
+  else if constexpr (R < MI + NI) na[R - NI] = lds_read128<(R - NI) * 16 * KB>(a_addr);
+}
+template <typename T, int MI, int NI, int JS, int BOUT, int M, bool RD = true> struct MmaIlv {
+  static constexpr int RPG = (MI + NI + MI * NI - 1) / (MI * NI);      // reads per MFMA gap (1 unless the block has fewer MFMAs than fragments)
+  static __device__ __forceinline__ void run(const u32x4 (&a)[MI], const u32x4 (&b)[NI], f32x4 (&acc)[MI][NI], u32x4 (&na)[MI], u32x4 (&nb)[NI],
+                                             uint32_t a_addr, uint32_t b_addr) {
+    // RD: this block requests fragments at all (not in the last K-step's second half)
+    constexpr int mi = M / NI, ni = M % NI;
+    mma16<T>(__builtin_bit_cast(uint4, a[mi]), __builtin_bit_cast(uint4, b[ni]), acc[mi][ni]);
+    if constexpr (RD && M * RPG < MI + NI) {
+      __builtin_amdgcn_sched_barrier(0);
+      ilv_read<MI, NI, JS, BOUT, M * RPG>(na, nb, a_addr, b_addr);
+      if constexpr (RPG > 1) ilv_read<MI, NI, JS, BOUT, M * RPG + 1>(na, nb, a_addr, b_addr);
+      static_assert(RPG <= 2, "at most two reads per gap");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MmaIlv<T, MI, NI, JS, BOUT, M + 1, RD>::run(a, b, acc, na, nb, a_addr, b_addr);
+  }
+};
+template <typename T, int MI, int NI, int JS, int BOUT, bool RD> struct MmaIlv<T, MI, NI, JS, BOUT, MI * NI, RD> {
+  static __device__ __forceinline__ void run(const u32x4 (&)[MI], const u32x4 (&)[NI], f32x4 (&)[MI][NI], u32x4 (&)[MI], u32x4 (&)[NI], uint32_t, uint32_t) {}
+};
+
 // NT form of the wave-specialised loop (same contract as tile_gemm_pipe, 512 threads; s0 / s1 must have been initialised
 // with tid & 255, so that loader wave w + 4 issues the pieces wave w issues in the 256-thread form).
 // The two roles as separate functions (a caller that gives the roles different work around the loop -- the fused backward step, whose
 // loader waves hold prefetched epilogue operands in their otherwise idle registers -- branches ONCE on the wave index and calls one of them;
 // each must be followed by the closing ws_barrier() that tile_gemm_ws issues).
 template <typename T, int BM, int BN, int NBUF>
-__device__ __forceinline__ void tile_gemm_ws_loader(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int lwave) {
+__device__ __forceinline__ void tile_gemm_ws_loader(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int lwave, int dbg = 0) {
   constexpr int LPS = (BM + BN) * 8 / 256;
   static_assert((NBUF - 2) * LPS < 64, "vmcnt range");
   const int nk = s0.nk + s1.nk;
+#ifdef MVAE_TUNING
+  const bool issue = !(dbg & 8);            // diagnostic build, MVAE_DBG bit 3: the loader waves keep the barriers but move nothing
+#else
+  constexpr bool issue = true;
+#endif
 #pragma unroll
   for (int s = 0; s < NBUF - 1; ++s)
-    if (s < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, s, lwave);
+    if (s < nk && issue) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, s, lwave);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + NBUF - 2 < nk) wait_vmcnt<(NBUF - 2) * LPS>();
     else wait_vmcnt<0>();
     ws_barrier();                                                       // barrier(kt)
-    if (kt + NBUF - 1 < nk) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, lwave);
+    if (kt + NBUF - 1 < nk && issue) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, lwave);
   }
 }
-template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT>
-__device__ __forceinline__ void tile_gemm_ws_consumer(char* smem, int nk, int arow0, int brow0, f32x4 (&acc)[MI][NI], int lane) {
+// Loader loop with a TAIL: right after the last stage has been issued the wave issues NTAIL more vector loads of its own (`tail()`: operands
+// of the caller's epilogue, whose latency then runs under the last NBUF - 1 K-steps instead of in front of the first).  They are the
+// YOUNGEST entries of the wave's memory queue, so the counted waits of the remaining iterations allow for them: in iteration
+// nk - NBUF + j (j = 1 .. NBUF - 1) stage kt has landed once at most (NBUF - 1 - j) stages + NTAIL loads are outstanding.
+// NTAIL must be exact (a smaller real count would let a stage be read before it has landed).  Requires nk >= NBUF.
+template <typename T, int BM, int BN, int NBUF, int NTAIL, typename Tail>
+__device__ __forceinline__ void tile_gemm_ws_loader_tail(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int lwave, Tail tail) {
+  constexpr int LPS = (BM + BN) * 8 / 256;
+  static_assert((NBUF - 2) * LPS + NTAIL < 64, "vmcnt range");
+  static_assert(NBUF == 4, "tail waits written out for a ring of four");
+  const int nk = s0.nk + s1.nk;
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s) pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, s, lwave);
+  for (int kt = 0; kt <= nk - NBUF; ++kt) {
+    wait_vmcnt<(NBUF - 2) * LPS>();
+    ws_barrier();                                                       // barrier(kt)
+    pipe_issue_stage<BM, BN, NBUF>(smem, s0, s1, kt + NBUF - 1, lwave);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");                                        // the tail loads stay behind the last stage's
+  tail();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  wait_vmcnt<2 * LPS + NTAIL>(); ws_barrier();                          // barrier(nk - 3)
+  wait_vmcnt<1 * LPS + NTAIL>(); ws_barrier();                          // barrier(nk - 2)
+  wait_vmcnt<NTAIL>(); ws_barrier();                                    // barrier(nk - 1)
+}
+template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT, bool ILV = false>
+__device__ __forceinline__ void tile_gemm_ws_consumer(char* smem, int nk, int arow0, int brow0, f32x4 (&acc)[MI][NI], int lane, int dbg = 0) {
+#ifdef MVAE_TUNING
+  // diagnostic build: MVAE_DBG bit 4 = no MFMAs, bit 5 = no fragment reads (barriers kept) -- which side of the hand-off sets the K-step
+  const bool do_mma = !(dbg & 16), do_rd = !(dbg & 32);
+#else
+  constexpr bool do_mma = true, do_rd = true;
+#endif
   constexpr int STAGE = (BM + BN) * KB;
   static_assert(MI + NI <= 15, "lgkmcnt range");
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
@@ -629,34 +700,65 @@ __device__ __forceinline__ void tile_gemm_ws_consumer(char* smem, int nk, int ar
   }
   u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
   ws_barrier();                                                         // barrier(0)
+  if (ILV && do_mma && do_rd) {            // (the diagnostic build's partial loops take the blocked form below)
   FragRead<0, MI, 16 * KB>::run(a0, lds0 + a_lane[0]);
   FragReadB<0, NI, JS, BOUT>::run(b0, lds0 + b_lane[0]);
+  wait_lgkmcnt<0>();
   for (int kt = 0; kt < nk; ++kt) {
     const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
+    // first half of stage kt on (a0, b0); the second-half fragments (a1, b1) of the same stage are requested in its first MFMA gaps
+    MmaIlv<T, MI, NI, JS, BOUT, 0>::run(a0, b0, acc, a1, b1, st + a_lane[1], st + b_lane[1]);
+    wait_lgkmcnt<0>();                                                  // every read of stage kt is done
+    if (kt + 1 < nk) {
+      ws_barrier();                                                     // barrier(kt + 1)
+      const uint32_t sn = lds0 + (uint32_t)(((kt + 1) % NBUF) * STAGE);
+      // second half of stage kt on (a1, b1); the first-half fragments of stage kt + 1 are requested in its first MFMA gaps
+      MmaIlv<T, MI, NI, JS, BOUT, 0>::run(a1, b1, acc, a0, b0, sn + a_lane[0], sn + b_lane[0]);
+      wait_lgkmcnt<0>();
+    } else {
+      MmaIlv<T, MI, NI, JS, BOUT, 0, false>::run(a1, b1, acc, a0, b0, 0u, 0u);      // last K-step: nothing left to request
+    }
+  }
+  } else {
+  if (do_rd) {
+  FragRead<0, MI, 16 * KB>::run(a0, lds0 + a_lane[0]);
+  FragReadB<0, NI, JS, BOUT>::run(b0, lds0 + b_lane[0]);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint32_t st = lds0 + (uint32_t)((kt % NBUF) * STAGE);
+    if (do_rd) {
     FragRead<0, MI, 16 * KB>::run(a1, st + a_lane[1]);
     FragReadB<0, NI, JS, BOUT>::run(b1, st + b_lane[1]);
+    }
     wait_lgkmcnt<MI + NI>();                                            // first half arrived, second half in flight
+    if (do_mma) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         mma16<T>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
+    }
     wait_lgkmcnt<0>();                                                  // every read of stage kt is done
     if (kt + 1 < nk) {
       ws_barrier();                                                     // barrier(kt + 1)
       const uint32_t sn = lds0 + (uint32_t)(((kt + 1) % NBUF) * STAGE);
+      if (do_rd) {
       FragRead<0, MI, 16 * KB>::run(a0, sn + a_lane[0]);
       FragReadB<0, NI, JS, BOUT>::run(b0, sn + b_lane[0]);
+      }
     }
+    if (do_mma) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         mma16<T>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
+    }
+  }
   }
 }
 
-template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT>
+template <typename T, int BM, int BN, int MI, int NI, int NBUF, int JS, int BOUT, bool ILV = false>
 __device__ __forceinline__ void tile_gemm_ws(char* smem, const PipeSeg<BM, BN>& s0, const PipeSeg<BM, BN>& s1, int arow0, int brow0,
                                              f32x4 (&acc)[MI][NI], int tid) {
   const int lane = tid & 63;
@@ -664,7 +766,7 @@ __device__ __forceinline__ void tile_gemm_ws(char* smem, const PipeSeg<BM, BN>& 
   const int nk = s0.nk + s1.nk;
   if (nk <= 0) return;
   if (wave >= 4) tile_gemm_ws_loader<T, BM, BN, NBUF>(smem, s0, s1, wave - 4);
-  else tile_gemm_ws_consumer<T, BM, BN, MI, NI, NBUF, JS, BOUT>(smem, nk, arow0, brow0, acc, lane);
+  else tile_gemm_ws_consumer<T, BM, BN, MI, NI, NBUF, JS, BOUT, ILV>(smem, nk, arow0, brow0, acc, lane);
   ws_barrier();
 }
 
