@@ -818,9 +818,6 @@ __device__ __forceinline__ void pipe_tn2_issue(char* smem, const PipeSegTN2& s, 
 #endif
 }
 
-#ifndef MVAE_TN_ILV
-#define MVAE_TN_ILV 1
-#endif
 // Phase 1 of a 256 x 256 TN K-step with the NEXT half's fragment reads interleaved: MFMA m (mi = m / 4, ni = m % 4) on (a0, b0) is followed,
 // for m < 24, by ONE ds_read_b64_tr_b16 -- read r = m fills half (r & 1) of fragment r >> 1 of the second K-half (fragments 0-7 = a1, 8-11 = b1).
 // In a block in front of the MFMAs those 24 reads cost their issue slots on top of the matrix pipe's time (the waves issue in order).
@@ -843,49 +840,6 @@ template <int M> struct TnIlv {
 template <> struct TnIlv<32> {
   static __device__ __forceinline__ void run(const u32x4 (&)[8], const u32x4 (&)[4], f32x4 (&)[8][4], u32x2 (&)[12], u32x2 (&)[12], const uint32_t (&)[8],
                                              const uint32_t (&)[4], uint32_t) {}
-};
-// one of the 8 pieces (0-3: A, 4-7: B) a wave contributes to a stage
-template <int P> __device__ __forceinline__ void pipe_tn2_issue_piece(char* smem, const PipeSegTN2& s, int st, int wave) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  char* stage = smem + (st & 1) * 65536;
-  constexpr int i = P & 3;
-  lds_void_t* dst = (lds_void_t*)(stage + (P < 4 ? 0 : 32768) + (i * 8 + wave) * 1024);
-  if constexpr (P < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(s.ra, dst, 16, s.offA[i] + (uint32_t)st * s.kstepA, 0, 0, 0);
-  else __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rb, dst, 16, s.offB[i] + (uint32_t)st * s.kstepB, 0, 0, 0);
-#endif
-}
-// Phase 1 with reads AND the refill spread over its 32 MFMA gaps, staggered between the two waves of a SIMD (waves w and w + 4), ONE code path:
-//   gaps 0-7: early waves (0-3) one LDS-DMA piece each;  gaps 8-15: two reads each;  gaps 16-23: one read each + late waves (4-7) one piece each.
-// An LDS-DMA piece holds its wave for 60-180 issue cycles; issued back to back behind the barrier by all eight waves at once those
-// cycles came straight out of the matrix pipe's time -- now the other wave of the SIMD is in a stretch of plain MFMAs meanwhile.
-template <int R> __device__ __forceinline__ void tn_ilv_read(u32x2 (&lo)[12], u32x2 (&hi)[12], const uint32_t (&addrA)[8], const uint32_t (&addrB)[4], uint32_t st) {
-  constexpr int F = R >> 1;
-  const uint32_t ad = st + (F < 8 ? addrA[F < 8 ? F : 0] : addrB[F < 8 ? 0 : F - 8]);
-  if constexpr ((R & 1) == 0) lo[F] = lds_read_tr64<32 * 512>(ad);
-  else hi[F] = lds_read_tr64<32 * 512 + 4 * 512>(ad);
-}
-template <int M> struct TnIlv2 {
-  static __device__ __forceinline__ void run(const u32x4 (&a0)[8], const u32x4 (&b0)[4], f32x4 (&acc)[8][4], u32x2 (&lo)[12], u32x2 (&hi)[12],
-                                             const uint32_t (&addrA)[8], const uint32_t (&addrB)[4], uint32_t st, char* smem, const PipeSegTN2& s,
-                                             int next_early, int next_late, int wave) {
-    constexpr int mi = M / 4, ni = M % 4;
-    mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
-    if constexpr (M < 24) {
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (M < 8) { if (next_early >= 0) pipe_tn2_issue_piece<M>(smem, s, next_early, wave); }          // wave-uniform
-      else if constexpr (M < 16) { tn_ilv_read<2 * (M - 8)>(lo, hi, addrA, addrB, st); tn_ilv_read<2 * (M - 8) + 1>(lo, hi, addrA, addrB, st); }
-      else {
-        tn_ilv_read<M>(lo, hi, addrA, addrB, st);
-        if (next_late >= 0) pipe_tn2_issue_piece<M - 16>(smem, s, next_late, wave);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    TnIlv2<M + 1>::run(a0, b0, acc, lo, hi, addrA, addrB, st, smem, s, next_early, next_late, wave);
-  }
-};
-template <> struct TnIlv2<32> {
-  static __device__ __forceinline__ void run(const u32x4 (&)[8], const u32x4 (&)[4], f32x4 (&)[8][4], u32x2 (&)[12], u32x2 (&)[12], const uint32_t (&)[8],
-                                             const uint32_t (&)[4], uint32_t, char*, const PipeSegTN2&, int, int, int) {}
 };
 // smem: 2 x 64 KiB.  wm in {0,1}, wn in {0..3}.
 // COLSUM variant: the column sums of A (sum_k A[k][m], the bias gradient when A = dG) ride along.  The 16 (tile column, wave column)
@@ -912,7 +866,6 @@ __device__ __forceinline__ void tile_gemm_tn_256(char* smem, const PipeSegTN2& s
   uint32_t addrS[1];
   addrS[0] = (uint32_t)(8 * g + q) * 512u + ((((uint32_t)(wm * 8 + (cs_mi & 7))) ^ f) << 5) + (uint32_t)pp * 8u + (cs_half == 1 ? 32u * 512u : 0u);
   pipe_tn2_issue(smem, s, 0, wave);
-#if MVAE_TN_ILV
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<0>();                                         // my pieces of stage kt have landed
     ws_barrier();                                            // everyone's have; nobody still reads stage kt-1
@@ -922,18 +875,12 @@ __device__ __forceinline__ void tile_gemm_tn_256(char* smem, const PipeSegTN2& s
     FragReadTN<0, 8, 512>::template run<0>(a0, addrA, st);
     FragReadTN<0, 4, 512>::template run<0>(b0, addrB, st);
     if constexpr (COLSUM) FragReadTN<0, 1, 512>::template run<0>(as, addrS, st);
-#if MVAE_TN_ILV == 2
-    wait_lgkmcnt<0>();
-    const int next = (kt + 1 < nk) ? kt + 1 : -1;            // refill of the buffer stage kt-1 used, spread over phase 1
-    TnIlv2<0>::run(a0, b0, acc, lo, hi, addrA, addrB, st, smem, s, wave < 4 ? next : -1, wave >= 4 ? next : -1, wave);
-#else
     // the refill of the other buffer goes out BEHIND the first half's reads: their LDS latency runs under the LDS-DMA issue
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     if (kt + 1 < nk) pipe_tn2_issue(smem, s, kt + 1, wave);  // into the buffer stage kt-1 used
     wait_lgkmcnt<0>();
     TnIlv<0>::run(a0, b0, acc, lo, hi, addrA, addrB, st);
-#endif
     if constexpr (COLSUM) {
       if (cs_half >= 0) mma16<bf16_t>(__builtin_bit_cast(uint4, as[0]), ones, accb);      // wave-uniform
     }
@@ -942,36 +889,6 @@ __device__ __forceinline__ void tile_gemm_tn_256(char* smem, const PipeSegTN2& s
     for (int i = 0; i < 8; ++i) a1[i] = u32x4{lo[i][0], lo[i][1], hi[i][0], hi[i][1]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) b1[i] = u32x4{lo[8 + i][0], lo[8 + i][1], hi[8 + i][0], hi[8 + i][1]};
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        mma16<bf16_t>(__builtin_bit_cast(uint4, a1[mi]), __builtin_bit_cast(uint4, b1[ni]), acc[mi][ni]);
-  }
-  ws_barrier();
-  return;
-#endif
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt<0>();                                         // my pieces of stage kt have landed
-    ws_barrier();                                            // everyone's have; nobody still reads stage kt-1
-    if (kt + 1 < nk) pipe_tn2_issue(smem, s, kt + 1, wave);  // into the buffer stage kt-1 used
-    const uint32_t st = lds0 + (uint32_t)((kt & 1) * 65536);
-    u32x4 a0[8], b0[4], a1[8], b1[4], as[1];
-    FragReadTN<0, 8, 512>::template run<0>(a0, addrA, st);
-    FragReadTN<0, 4, 512>::template run<0>(b0, addrB, st);
-    if constexpr (COLSUM) FragReadTN<0, 1, 512>::template run<0>(as, addrS, st);
-    wait_lgkmcnt<0>();
-    FragReadTN<0, 8, 512>::template run<32 * 512>(a1, addrA, st);
-    FragReadTN<0, 4, 512>::template run<32 * 512>(b1, addrB, st);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        mma16<bf16_t>(__builtin_bit_cast(uint4, a0[mi]), __builtin_bit_cast(uint4, b0[ni]), acc[mi][ni]);
-    if constexpr (COLSUM) {
-      if (cs_half >= 0) mma16<bf16_t>(__builtin_bit_cast(uint4, as[0]), ones, accb);      // wave-uniform
-    }
-    wait_lgkmcnt<0>();
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
