@@ -1422,8 +1422,10 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     struct Cand { int bm, bn, ns, key; };
     // (128 x 128, 1) = unsplit, gate-derivative epilogue fused into the wave-specialised GEMM kernel: no partial tiles at all; wins once it
     // fills the chip by itself (B = 1024: 31.7 vs 32.4 ms / step in situ against (256 x 128, 2); at B = 512 it has 128 workgroups: 70 vs 49 us)
-    static const Cand cand[5] = {{128, 128, 1, 1281}, {256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
-    for (int c = 0; c < 5 && !nsplit; ++c) {
+    // (128 x 64, 1) = the same fused kernel on half-width tiles: B = 512 at 4 x 1024 is 256 of them -- one launch of 3 MB per CU instead of the
+    // (128 x 128, 2) GEMM + element-wise pair (MVAE_BWD_SPLIT=641 forces it)
+    static const Cand cand[6] = {{128, 128, 1, 1281}, {128, 64, 1, 641}, {256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
+    for (int c = 0; c < 6 && !nsplit; ++c) {
       if (B % cand[c].bm || (cand[c].ns == 4 && (4 * H) % (2 * ke))) continue;
       if (drop && cand[c].ns == 1) continue;      // the unsplit wave-specialised instantiation carries no dropout factor (DROP = false): never with a mask
       const long wgs = (long)(B / cand[c].bm) * (H / cand[c].bn) * cand[c].ns * NL;
@@ -1518,6 +1520,11 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     if (big_fused) {
       block = dim3(512);
       const int pref = tune_int("MVAE_BWD_PREF", 1);           // 0: the round-2 form (operands requested inside the epilogue), A/B knob
+      if (BN == 64) {
+        if (d->dy) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true, false, 0, 1>));
+        else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true, false, 0, 2>));
+        continue;
+      }
       if (!pref) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0>));
       else if (d->dy) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0, 1>));
       else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 128, 4, true, false, 0, 2>));

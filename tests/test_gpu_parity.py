@@ -283,7 +283,7 @@ def test_lstm_tile_variants_vs_oracle(env, monkeypatch):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("split", ["0", "2", "2562", "1284", "644", "1281"])
+@pytest.mark.parametrize("split", ["0", "2", "2562", "1284", "644", "1281", "641"])
 def test_lstm_bwd_split_segment_schedule(split, monkeypatch):
     """Backward with the contraction split across workgroups -- by K-segment (128x128 or 256x128 partial tiles) or by half segment
     (4 partial tiles per output: the small-batch schedules) + element-wise second launch -- vs the fused single-launch form."""
