@@ -122,7 +122,7 @@ def _lstm_case(dt, T, B, H, NL, In, seed=2):
     return errs
 
 
-@pytest.mark.parametrize("split", ["1", "0", "2", "1284", "644", "1281", "2562"])
+@pytest.mark.parametrize("split", ["1", "0", "2", "1284", "644", "1281", "641", "2562"])
 def test_lstm_bwd_output_gradient_as_a_product(split, monkeypatch):
     """mvae_rnn_bwd with dy given as dy_a . dy_w^T (contracted by the top layer's cell as its second K-segment) against the same call with the
     materialised fp32 dy = dy_a . dy_w^T, in every backward schedule (fused, 2- and 4-way split, unsplit 128 x 128, 256 x 128)."""

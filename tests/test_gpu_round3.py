@@ -167,6 +167,29 @@ def test_moses_dropout_mask_reaches_every_backward_schedule(split, B, monkeypatc
     assert not bad, bad
 
 
+@pytest.mark.parametrize("split", ["1281", "641"])
+def test_moses_without_dropout_on_the_fused_prefetching_backward(split, monkeypatch):
+    """A GRU stack WITHOUT a dropout mask may run its backward on the unsplit wave-specialised kernel (128 x 128 tiles, or 128 x 64 -- the form
+    large batches pick): GRU cells there take the operand prefetch in front of the ring, the zero gate-slot blocks are skipped as K holes, and
+    lengths mask the finished rows.  Forced at B = 128 and checked against the oracle."""
+    monkeypatch.setenv("MVAE_BWD_SPLIT", split)
+    v, params, model = _moses_model(torch.bfloat16, seed=12)
+    model.train()
+    model.d_dropout = 0.0
+    rs = np.random.RandomState(16)
+    B = 128
+    lens = sorted(rs.randint(8, 24, size=B).tolist(), reverse=True)
+    seqs = [np.concatenate([[v.bos], rs.randint(0, 26, size=n), [v.eos]]).astype(np.int64) for n in lens]
+    eps = rs.standard_normal((B, 160)).astype(np.float32)
+    kl, recon, *_ = model([torch.from_numpy(s) for s in seqs], torch.from_numpy(eps).to(dev))
+    (0.5 * kl + recon).backward()
+    ref = O.moses_forward({k: a.astype(np.float64) for k, a in params.items()}, seqs, eps.astype(np.float64), v.pad)
+    assert abs(float(recon) - ref["recon"]) < 5e-3 * abs(ref["recon"])
+    rg = ref["grads_for"](0.5)
+    bad = {k: rel(p_.grad.cpu().numpy(), rg[k]) for k, p_ in model.named_parameters() if rel(p_.grad.cpu().numpy(), rg[k]) > 8e-2}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_moses_gradient_through_logits_stops_at_finished_positions(dtype):
     """Backpropagating through the returned logits `y` with ragged lengths: pad_packed_sequence (mosesvae.py:189) emits zeros at finished
