@@ -23,7 +23,7 @@ if torch.cuda.is_available():
 
 # ---------------------------------------------------------------------------------------------- MolecularVAE at bench sizes vs g2
 @pytest.mark.parametrize("dtype,tl,tr,tg", [(torch.float32, 1e-5, 1e-5, 5e-4), (torch.bfloat16, 1e-4, 5e-3, 5e-2)])
-@pytest.mark.parametrize("B", [1024, 512, 128])
+@pytest.mark.parametrize("B", [1024, 512, 256, 128])
 def test_bench_size_batch_tiled_from_the_reference_fixture(golden_dir, B, dtype, tl, tr, tg):
     """The kernels bench.py runs -- lstm_step_fwd_gm_kernel<256,256,2> / the fused 128 x 128 backward at B=1024, the wave-specialised
     tiles + split backward at B=512, the gate-major 32 x 64 tile + 4-way split at b=128, the grouped full-K weight-gradient GEMMs
