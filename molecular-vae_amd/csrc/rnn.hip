@@ -1169,6 +1169,7 @@ static inline const char* adv(const void* p, long elems, int dtype) {
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st);
+int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st);
 
 int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (!d) return MVAE_ERR_INVALID;
@@ -1202,6 +1203,11 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   // narrow f32 stacks (the encoder): row-resident schedule, one launch per layer instead of one per wavefront step
   if (!drop && tune_int("MVAE_ROWRES", 1)) {
     const int rc = rnn_rowres_fwd(d, st);
+    if (rc != MVAE_ERR_UNSUPPORTED) return rc;
+  }
+  // one-layer bf16 GRU(256) over a token table (the MOSES encoder): row-resident as well, ONE launch for the whole sequence
+  if (!drop && tune_int("MVAE_GRU_ROWRES", 1)) {
+    const int rc = rnn_gru_rowres_fwd(d, st);
     if (rc != MVAE_ERR_UNSUPPORTED) return rc;
   }
   // row tile: the largest of 128 / 64 / 32 that still gives >= 256 workgroups per launch (the f32 MFMA rate is 1/16 of bf16, so

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include "common.hpp"
 #include "kernels.hpp"
+#include "tile_pipe.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -310,6 +311,186 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) 
   }
 }
 
+// =====================================================================================================================
+// Row-resident GRU for ONE-layer bf16 stacks of H = 256 whose input projection is a token table (the MOSES encoder: GRU(V -> 256),
+// mosesvae.py:142-156 with the embedding folded into tbl[V][4H]).  The wavefront schedule pays one launch per time step for
+// 0.4 GFLOP (8 us each, 59 + 59 launches of a 6 ms step).  Here a workgroup of 8 waves owns 16 batch rows for the whole sequence:
+//   * W_hh (768 x 256 bf16 = 393 KB) lives in REGISTERS for the whole pass: wave w holds, for hidden units 32 w .. 32 w + 31, the rows of
+//     its r and z gates as B fragments of v_mfma_f32_16x16x32_bf16 (2 gates x 2 unit tiles x 8 K-blocks x 4 VGPRs = 128 VGPRs); the n gate's
+//     fragments (W_hn, 128 KB) sit in LDS in fragment order and stream through registers with the A fragments;
+//   * h_{t-1} of the 16 rows sits in LDS as bf16 (the A operand, 8 ds_read_b128 per wave and step), double-buffered: ONE barrier per step;
+//   * the accumulator layout gives every lane rows 4 q .. 4 q + 3 of ONE hidden unit for all three gates, so the whole cell update
+//     (table row + bias, sigmoid / tanh, length mask, fp32 state) stays in the lane's registers.
+// Gate slots, masks and saved tensors exactly as lstm_step_fwd_kernel's GRU branch (rnn.hip): slots [r | z | W_in x + b_in | W_hn h + b_hn],
+// a finished row keeps its state and emits zeros.
+constexpr int GR_ROWS = 16;        // MFMA rows of the A tile
+constexpr int GR_RPL = 2;          // real batch rows per lane (of its 4 accumulator rows): 8 batch rows per workgroup
+__device__ __forceinline__ bf16_t f2bf_t(float f) { bf16_t r; r.x = f2bf(f); return r; }
+// the bf16 step kernels' activation forms (rnn.hip act_sigmoid<bf16_t> / act_tanh<bf16_t>): same numbers on either schedule
+__device__ __forceinline__ float act_sigmoid_bf(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float act_tanh_bf(float x) { return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)), 1.f); }
+struct GruRowF {
+  const bf16_t* w_hh; long ldw;      // [4H][ldw] packed 4-slot (slot 2 rows are a zero block and never read)
+  const float* bias;                 // [4H] or nullptr
+  const float* tbl; const long* idx; long idx_ld; int tbl_rows;      // addend of step t, row b: tbl[idx[b * idx_ld + t]][4H] (slots 0-2)
+  const int* lengths;                // [B] or nullptr
+  const bf16_t* h0; long ldh0;       // [B][ldh0] or nullptr (zeros)
+  bf16_t* hs; long ldh;              // out [T][B][ldh]
+  bf16_t* gates;                     // out [T][B][4H] (r, z, n, W_hn h + b_hn) or nullptr
+  float* hstate;                     // out [2][B][H]: slot (T - 1) & 1 receives the final state
+  int T, B;
+};
+
+// K loop of one step: fragment set kb & 1 holds the A fragment (h_{t-1}) and the W_hn fragments of K-block kb; the reads of block kb + 1
+// are in flight under the MFMAs of block kb (three ds_read_b128 per block: the counted wait lets exactly those three stay outstanding)
+template <int KB_, int KBLK, int UT> struct GruFrag {
+  static __device__ __forceinline__ void run(u32x4 (&af)[2], u32x4 (&wn)[2][UT], uint32_t ab, uint32_t wnb, const uint4 (&wf)[2][UT][KBLK], f32x4 (&acc)[3][UT]) {
+    constexpr int c = KB_ & 1, n = c ^ 1;
+    if constexpr (KB_ + 1 < KBLK) {
+      af[n] = lds_read128<(KB_ + 1) * 64>(ab);
+#pragma unroll
+      for (int j = 0; j < UT; ++j) wn[n][j] = lds_read128<0>(wnb + (uint32_t)((j * KBLK + KB_ + 1) * 1024));
+      wait_lgkmcnt<1 + UT>();
+    } else wait_lgkmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < UT; ++j) {
+      mma16<bf16_t>(__builtin_bit_cast(uint4, af[c]), wf[0][j][KB_], acc[0][j]);
+      mma16<bf16_t>(__builtin_bit_cast(uint4, af[c]), wf[1][j][KB_], acc[1][j]);
+      mma16<bf16_t>(__builtin_bit_cast(uint4, af[c]), __builtin_bit_cast(uint4, wn[c][j]), acc[2][j]);
+    }
+    GruFrag<KB_ + 1, KBLK, UT>::run(af, wn, ab, wnb, wf, acc);
+  }
+};
+template <int KBLK, int UT> struct GruFrag<KBLK, KBLK, UT> {
+  static __device__ __forceinline__ void run(u32x4 (&)[2], u32x4 (&)[2][UT], uint32_t, uint32_t, const uint4 (&)[2][UT][KBLK], f32x4 (&)[3][UT]) {}
+};
+template <int KB0, int KBLK, int UT>
+__device__ __forceinline__ void gru_frag_step(u32x4 (&af)[2], u32x4 (&wn)[2][UT], uint32_t ab, uint32_t wnb, const uint4 (&wf)[2][UT][KBLK], f32x4 (&acc)[3][UT]) {
+  af[0] = lds_read128<0>(ab);
+#pragma unroll
+  for (int j = 0; j < UT; ++j) wn[0][j] = lds_read128<0>(wnb + (uint32_t)(j * KBLK * 1024));
+  GruFrag<0, KBLK, UT>::run(af, wn, ab, wnb, wf, acc);
+}
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
+  static_assert(H == 256, "8 waves x 32 hidden units");
+  constexpr int KBLK = H / 32, LDA = H + 8, UT = 2, RPL = GR_RPL;          // A rows padded by 16 bytes: the 16 rows of a fragment read start on different banks
+  constexpr int WN_BYTES = (H / 16) * KBLK * 1024;           // the n gate's W_hn fragments: [unit tile][K-block][lane] x 16 bytes = 128 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t (*abuf)[GR_ROWS][LDA] = reinterpret_cast<bf16_t (*)[GR_ROWS][LDA]>(smem + WN_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
+  const int r0 = blockIdx.x * (4 * RPL), B = p.B, T = p.T;   // RPL of the 4 accumulator rows of a lane are real batch rows (registers: gx / state per row)
+  const int u0 = 32 * wave + lc;                              // this lane's hidden units: u0 and u0 + 16; its batch rows: r0 + 4 lq + i
+  // ---- weights: fragment (gate s, unit tile j, K-block kb) = W[slot_s * H + u0 + 16 j][32 kb + 8 lq .. + 8].
+  // r and z stay in registers (128 VGPRs); the n gate's go to LDS in fragment order (a wave reads back only what it wrote itself)
+  uint4 wf[2][UT][KBLK];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int j = 0; j < UT; ++j) {
+      const bf16_t* wr = p.w_hh + (long)((s == 2 ? 3 : s) * H + u0 + 16 * j) * p.ldw + 8 * lq;
+#pragma unroll
+      for (int kb = 0; kb < KBLK; ++kb) {
+        const uint4 v = *reinterpret_cast<const uint4*>(wr + 32 * kb);
+        if (s < 2) wf[s][j][kb] = v;
+        else *reinterpret_cast<uint4*>(smem + (((2 * wave + j) * KBLK + kb) * 64 + lane) * 16) = v;
+      }
+    }
+  float* bias_s = reinterpret_cast<float*>(smem + WN_BYTES + 2 * GR_ROWS * LDA * 2);      // [4][H] in LDS: read back per step (registers are short)
+  for (int i = tid; i < 4 * H; i += 512) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+  int len[RPL]; float hst[RPL][UT];
+  const int rbase = r0 + RPL * lq;                            // rows rbase .. rbase + RPL - 1 (clamped to B - 1 for loads, never stored beyond B)
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    const int rc = (rbase + i < B) ? rbase + i : B - 1;
+    len[i] = p.lengths ? p.lengths[rc] : T;
+#pragma unroll
+    for (int j = 0; j < UT; ++j) hst[i][j] = p.h0 ? bf2f(p.h0[(long)rc * p.ldh0 + u0 + 16 * j].x) : 0.f;
+  }
+  auto token = [&](int i, int t) -> int {                     // clamped table row of (row i, step t)
+    const int rc = (rbase + i < B) ? rbase + i : B - 1;
+    const long id = p.idx[(long)rc * p.idx_ld + t];
+    return (int)(id < 0 ? 0 : (id >= p.tbl_rows ? p.tbl_rows - 1 : id));
+  };
+  __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): the weight registers are complete before the time loop (see lstm_rowres_fwd_kernel)
+  for (int i = tid; i < 2 * GR_ROWS * LDA / 2; i += 512) reinterpret_cast<uint32_t*>(&abuf[0][0][0])[i] = 0u;      // padding rows stay zero
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RPL; ++i)
+#pragma unroll
+    for (int j = 0; j < UT; ++j) abuf[0][4 * lq + i][u0 + 16 * j] = f2bf_t(hst[i][j]);      // A buffer of step 0: h_0
+  int tok[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) tok[i] = token(i, 0);
+  __syncthreads();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const uint32_t a_lane = lds0 + (uint32_t)WN_BYTES + (uint32_t)(lc * LDA * 2 + lq * 16);
+  const uint32_t wn_lane = lds0 + (uint32_t)((2 * wave * KBLK * 64 + lane) * 16);
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    // this step's table rows (requested first: they are needed only behind the MFMAs) and the next step's token ids
+    float gx[RPL][3][UT];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const float* tr = p.tbl + (long)tok[i] * 4 * H + u0;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < UT; ++j) gx[i][s][j] = tr[s * H + 16 * j];
+    }
+    if (t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) tok[i] = token(i, t + 1);
+    }
+    // ---- gh = h_{t-1} . W_hh^T for the wave's 32 units x 3 gates; A and W_hn fragments stream through two register sets
+    f32x4 acc[3][UT];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int j = 0; j < UT; ++j) acc[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t ab = a_lane + (uint32_t)(cur * GR_ROWS * LDA * 2);
+    u32x4 af[2], wn[2][UT];
+    gru_frag_step<0, KBLK, UT>(af, wn, ab, wn_lane, wf, acc);
+    // ---- cell update: RPL rows of two units per lane
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const int row = rbase + i;
+      const bool valid = t < len[i];
+#pragma unroll
+      for (int j = 0; j < UT; ++j) {
+        const int u = u0 + 16 * j;
+        const float pr = (acc[0][j][i] + bias_s[u]) + gx[i][0][j];
+        const float pz = (acc[1][j][i] + bias_s[H + u]) + gx[i][1][j];
+        const float pn = (0.f + bias_s[2 * H + u]) + gx[i][2][j];
+        const float ph = acc[2][j][i] + bias_s[3 * H + u];
+        const float gr = act_sigmoid_bf(pr), gz = act_sigmoid_bf(pz);
+        const float gn = act_tanh_bf(pn + gr * ph);
+        const float hn = (1.f - gz) * gn + gz * hst[i][j];
+        hst[i][j] = valid ? hn : hst[i][j];
+        const float hseq = valid ? hn : 0.f;
+        abuf[nxt][4 * lq + i][u] = f2bf_t(hst[i][j]);
+        if (row < B) {
+          p.hs[((long)t * B + row) * p.ldh + u] = f2bf_t(hseq);
+          if (p.gates) {
+            bf16_t* g4 = p.gates + ((long)t * B + row) * 4 * H + u;
+            g4[0] = f2bf_t(gr); g4[H] = f2bf_t(gz); g4[2 * H] = f2bf_t(gn); g4[3 * H] = f2bf_t(ph);
+          }
+        }
+      }
+    }
+    wait_lgkmcnt<0>();                                        // my LDS writes of h_t are done
+    ws_barrier();                                             // (no vmcnt wait: the stores of this step stay in flight)
+  }
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    const int row = rbase + i;
+#pragma unroll
+    for (int j = 0; j < UT; ++j)
+      if (row < B) p.hstate[((long)((T - 1) & 1) * B + row) * H + u0 + 16 * j] = hst[i][j];
+  }
+}
+
 }  // namespace
 
 // layers of one pass, sequentially; returns MVAE_ERR_UNSUPPORTED when the shape is not the one this schedule is built for
@@ -381,6 +562,31 @@ int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     dy = a.dx; dy_ld = H;
   }
   hipLaunchKernelGGL((lstm_rowres_bwd_all_kernel<H>), dim3((B + RR_ROWS - 1) / RR_ROWS), dim3(256), 0, st, all);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+// One-layer bf16 GRU(256) with a token-table addend (the MOSES encoder): row-resident forward, one launch for the whole sequence
+int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
+  constexpr int H = 256;
+  if (d->cell != MVAE_CELL_GRU || d->dtype != MVAE_BF16 || d->layers != 1 || d->H != H || d->x0 || d->add0 || !d->add_table || !d->add_index)
+    return MVAE_ERR_UNSUPPORTED;
+  if (d->drop_p > 0.f || !d->hs[0] || !d->cstate[0] || d->T < 1) return MVAE_ERR_UNSUPPORTED;
+  if (d->ldw_hh[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hh[0]) & 15)) return MVAE_ERR_UNSUPPORTED;
+  GruRowF a;
+  a.w_hh = reinterpret_cast<const bf16_t*>(d->w_hh[0]); a.ldw = d->ldw_hh[0];
+  a.bias = d->bias[0];
+  a.tbl = d->add_table; a.idx = reinterpret_cast<const long*>(d->add_index); a.idx_ld = d->add_index_ld; a.tbl_rows = d->add_table_rows;
+  a.lengths = d->lengths;
+  a.h0 = reinterpret_cast<const bf16_t*>(d->h0[0]); a.ldh0 = d->ldh0;
+  a.hs = reinterpret_cast<bf16_t*>(d->hs[0]); a.ldh = d->ldh;
+  a.gates = reinterpret_cast<bf16_t*>(d->gates[0]);
+  a.hstate = d->cstate[0];
+  a.T = d->T; a.B = d->B;
+  constexpr size_t lds = (size_t)(H / 16) * (H / 32) * 1024 + 2 * GR_ROWS * (H + 8) * sizeof(bf16_t) + 4 * H * sizeof(float);      // W_hn fragments + the double-buffered A rows + bias
+  static bool attr_set = false;
+  if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+  hipLaunchKernelGGL((gru_rowres_fwd_kernel<H>), dim3((d->B + 4 * GR_RPL - 1) / (4 * GR_RPL)), dim3(512), lds, st, a);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
