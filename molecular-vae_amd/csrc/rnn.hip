@@ -1360,6 +1360,7 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st) {
 }
 
 int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st);
+int rnn_gru_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st);
 size_t rnn_rowres_bwd_workspace(int layers, int T, int B, int H);
 
 size_t rnn_bwd_workspace_bytes(const mvae_rnn_bwd_desc* d) {
@@ -1394,6 +1395,10 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   if (drop && d->drop_p >= 1.f) return MVAE_ERR_INVALID;
   if (!drop && tune_int("MVAE_ROWRES", 1)) {
     const int rc = rnn_rowres_bwd(d, st);
+    if (rc != MVAE_ERR_UNSUPPORTED) return rc;
+  }
+  if (!drop && tune_int("MVAE_GRU_ROWRES", 1)) {             // one-layer bf16 GRU(256): row-resident, one launch (rnn_rowres.hip)
+    const int rc = rnn_gru_rowres_bwd(d, st);
     if (rc != MVAE_ERR_UNSUPPORTED) return rc;
   }
   // bf16: 64-row tiles (two workgroups per CU: one's epilogue runs under the other's main loop); f32: 32 x 32 tiles when the

@@ -491,6 +491,153 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
   }
 }
 
+// ---- backward of the same stack.  Walking t = T-1 .. 0 a workgroup keeps, for its 8 batch rows: the carried gradient dh in registers (fp32),
+// dG_{t+1}[r | z | n*r] as bf16 in LDS (the A operand of  dh_t += dG_{t+1} . W_hh, K = 3H: the zero gate-slot block is never stored), W_hh^T
+// for the wave's 32 output units as B fragments -- K-blocks of the r and z slots in registers (128 VGPRs), of the n*r slot in LDS (128 KB, fragment
+// order).  Gate-derivative math and masks exactly as bwd_cell_finish's GRU branch (rnn.hip); dG[t] goes to global for the weight-gradient GEMMs.
+struct GruRowB {
+  const bf16_t* w_hhT; long ldwT;    // [H][ldwT]: W_hh^T, columns = 4 gate slots x H
+  const bf16_t* gates;               // [T][B][4H] saved r, z, n, W_hn h + b_hn
+  const bf16_t* hs; long ldh;        // [T][B][ldh] forward outputs (h_{t-1} of step t = hs[t-1])
+  const bf16_t* h0; long ldh0;       // [B][ldh0] or nullptr
+  const float* dh_last;              // [B][H] gradient w.r.t. the final state, or nullptr
+  const float* dy; long dy_ld;       // [T*B][dy_ld] gradient w.r.t. the output sequence, or nullptr
+  const int* lengths;
+  bf16_t* dG; long ldg;              // out [T][B][ldg], 4 slots
+  int T, B;
+};
+constexpr int GRB_LDG = 3 * 256 + 8;
+
+template <int KB_, int NREG, int NK, int UT> struct GruFragB {
+  // K-blocks 0 .. NREG-1: W fragments in registers; NREG .. NK-1: streamed from LDS beside the A fragment
+  static __device__ __forceinline__ void run(u32x4 (&af)[2], u32x4 (&wl)[2][UT], uint32_t ab, uint32_t wlb, const uint4 (&wf)[UT][NREG], f32x4 (&acc)[UT]) {
+    constexpr int c = KB_ & 1, n = c ^ 1;
+    if constexpr (KB_ + 1 < NK) {
+      af[n] = lds_read128<(KB_ + 1) * 64>(ab);
+      if constexpr (KB_ + 1 >= NREG) {
+#pragma unroll
+        for (int j = 0; j < UT; ++j) wl[n][j] = lds_read128<0>(wlb + (uint32_t)((j * (NK - NREG) + KB_ + 1 - NREG) * 1024));
+        wait_lgkmcnt<1 + UT>();
+      } else wait_lgkmcnt<1>();
+    } else wait_lgkmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < UT; ++j) {
+      if constexpr (KB_ < NREG) mma16<bf16_t>(__builtin_bit_cast(uint4, af[c]), wf[j][KB_ < NREG ? KB_ : 0], acc[j]);
+      else mma16<bf16_t>(__builtin_bit_cast(uint4, af[c]), __builtin_bit_cast(uint4, wl[c][j]), acc[j]);
+    }
+    GruFragB<KB_ + 1, NREG, NK, UT>::run(af, wl, ab, wlb, wf, acc);
+  }
+};
+template <int NREG, int NK, int UT> struct GruFragB<NK, NREG, NK, UT> {
+  static __device__ __forceinline__ void run(u32x4 (&)[2], u32x4 (&)[2][UT], uint32_t, uint32_t, const uint4 (&)[UT][NREG], f32x4 (&)[UT]) {}
+};
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
+  static_assert(H == 256, "8 waves x 32 hidden units");
+  constexpr int KBH = H / 32, NK = 3 * KBH, NREG = 2 * KBH, UT = 2, RPL = GR_RPL, NROW = 4 * RPL, LDG = GRB_LDG;
+  constexpr int WL_BYTES = (H / 16) * KBH * 1024;             // the n*r slot's W fragments: [unit tile][K-block][lane] x 16 bytes = 128 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t (*gbuf)[NROW][LDG] = reinterpret_cast<bf16_t (*)[NROW][LDG]>(smem + WL_BYTES);      // dG_{t+1}[r | z | n*r] of the 8 rows, double-buffered
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
+  const int r0 = blockIdx.x * NROW, B = p.B, T = p.T;
+  const int u0 = 32 * wave + lc;
+  // ---- W_hh^T fragments: (unit tile j, K-block kb) = W_hhT[u0 + 16 j][kcol(kb) + 8 lq .. + 8], kcol = slot r / z / n*r (gate slots 0, 1, 3)
+  uint4 wf[UT][NREG];
+#pragma unroll
+  for (int j = 0; j < UT; ++j) {
+    const bf16_t* wr = p.w_hhT + (long)(u0 + 16 * j) * p.ldwT + 8 * lq;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+      const int kcol = (kb < KBH ? 0 : kb < 2 * KBH ? H : 3 * H) + 32 * (kb % KBH);
+      const uint4 v = *reinterpret_cast<const uint4*>(wr + kcol);
+      if (kb < NREG) wf[j][kb < NREG ? kb : 0] = v;
+      else *reinterpret_cast<uint4*>(smem + (((2 * wave + j) * KBH + (kb - NREG)) * 64 + lane) * 16) = v;
+    }
+  }
+  int len[RPL]; float dh[RPL][UT];
+  const int rbase = r0 + RPL * lq;
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    const int rc = (rbase + i < B) ? rbase + i : B - 1;
+    len[i] = p.lengths ? p.lengths[rc] : T;
+#pragma unroll
+    for (int j = 0; j < UT; ++j) dh[i][j] = p.dh_last ? p.dh_last[(long)rc * H + u0 + 16 * j] : 0.f;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): the weight registers are complete before the time loop
+  for (int i = tid; i < 2 * NROW * LDG / 2; i += 512) reinterpret_cast<uint32_t*>(&gbuf[0][0][0])[i] = 0u;      // dG_T = 0
+  // operands of step t: saved gates of (row i, unit tile j) and h_{t-1}
+  struct Ops { uint16_t g[RPL][UT][4]; uint16_t hp[RPL][UT]; };
+  auto load_ops = [&](int t, Ops& o) {
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const int rc = (rbase + i < B) ? rbase + i : B - 1;
+      const bf16_t* g4 = p.gates + ((long)t * B + rc) * 4 * H + u0;
+      const bf16_t* hp = (t > 0) ? p.hs + ((long)(t - 1) * B + rc) * p.ldh + u0 : (p.h0 ? p.h0 + (long)rc * p.ldh0 + u0 : nullptr);
+#pragma unroll
+      for (int j = 0; j < UT; ++j) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o.g[i][j][s] = g4[s * H + 16 * j].x;
+        o.hp[i][j] = hp ? hp[16 * j].x : (uint16_t)0;
+      }
+    }
+  };
+  Ops cur_ops;
+  load_ops(T - 1, cur_ops);
+  __syncthreads();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const int rr = ((lc & 3) < RPL) ? (lc >> 2) * RPL + (lc & 3) : 0;      // MFMA tile row lc -> real row (padding rows alias row 0: their results are unused)
+  const uint32_t a_lane = lds0 + (uint32_t)WL_BYTES + (uint32_t)(rr * LDG * 2 + lq * 16);
+  const uint32_t wl_lane = lds0 + (uint32_t)((2 * wave * KBH * 64 + lane) * 16);
+  for (int t = T - 1; t >= 0; --t) {
+    const int cur = (T - 1 - t) & 1, nxt = cur ^ 1;
+    Ops nxt_ops;
+    if (t > 0) load_ops(t - 1, nxt_ops);                      // next step's operands: in flight under this step
+    // ---- dh_t += dG_{t+1}[r | z | n*r] . W_hh  (zero at t = T - 1)
+    f32x4 acc[UT];
+#pragma unroll
+    for (int j = 0; j < UT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t ab = a_lane + (uint32_t)(cur * NROW * LDG * 2);
+    u32x4 af[2], wl[2][UT];
+    af[0] = lds_read128<0>(ab);
+    GruFragB<0, NREG, NK, UT>::run(af, wl, ab, wl_lane, wf, acc);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const int row = rbase + i;
+      const bool valid = t < len[i];
+#pragma unroll
+      for (int j = 0; j < UT; ++j) {
+        const int u = u0 + 16 * j;
+        float d = dh[i][j] + acc[j][i];
+        float dpr = 0.f, dpz = 0.f, dpn = 0.f, dpnr = 0.f, carry = d;
+        if (valid) {
+          if (p.dy && row < B) d += p.dy[((long)t * B + row) * p.dy_ld + u];
+          const float gr = bf2f(cur_ops.g[i][j][0]), gz = bf2f(cur_ops.g[i][j][1]), gn = bf2f(cur_ops.g[i][j][2]), nh = bf2f(cur_ops.g[i][j][3]);
+          const float hp = bf2f(cur_ops.hp[i][j]);
+          const float dn = d * (1.f - gz);
+          const float dz = d * (hp - gn);
+          dpn = dn * (1.f - gn * gn);
+          dpr = dpn * nh * gr * (1.f - gr);
+          dpz = dz * gz * (1.f - gz);
+          dpnr = dpn * gr;
+          carry = d * gz;
+        }
+        dh[i][j] = carry;
+        const bf16_t br = f2bf_t(dpr), bz = f2bf_t(dpz), bnr = f2bf_t(dpnr);
+        bf16_t* gl = &gbuf[nxt][RPL * lq + i][u];
+        gl[0] = br; gl[H] = bz; gl[2 * H] = bnr;
+        if (row < B) {
+          bf16_t* d4 = p.dG + ((long)t * B + row) * p.ldg + u;
+          d4[0] = br; d4[H] = bz; d4[2 * H] = f2bf_t(dpn); d4[3 * H] = bnr;
+        }
+      }
+    }
+    if (t > 0) cur_ops = nxt_ops;
+    wait_lgkmcnt<0>();
+    ws_barrier();
+  }
+}
+
 }  // namespace
 
 // layers of one pass, sequentially; returns MVAE_ERR_UNSUPPORTED when the shape is not the one this schedule is built for
@@ -587,6 +734,30 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
   hipLaunchKernelGGL((gru_rowres_fwd_kernel<H>), dim3((d->B + 4 * GR_RPL - 1) / (4 * GR_RPL)), dim3(512), lds, st, a);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+// backward of the same stack: one launch; the weight / bias / table gradients stay with the caller's GEMMs over dG
+int rnn_gru_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
+  constexpr int H = 256;
+  if (d->cell != MVAE_CELL_GRU || d->dtype != MVAE_BF16 || d->layers != 1 || d->H != H || d->dy_a || d->drop_p > 0.f) return MVAE_ERR_UNSUPPORTED;
+  if (d->dh0[0] || !d->gates[0] || !d->hs[0] || !d->dG[0] || !d->w_hhT[0] || d->T < 1) return MVAE_ERR_UNSUPPORTED;
+  if (d->ldw_hhT[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hhT[0]) & 15) || d->ldg < 4L * H) return MVAE_ERR_UNSUPPORTED;
+  GruRowB a;
+  a.w_hhT = reinterpret_cast<const bf16_t*>(d->w_hhT[0]); a.ldwT = d->ldw_hhT[0];
+  a.gates = reinterpret_cast<const bf16_t*>(d->gates[0]);
+  a.hs = reinterpret_cast<const bf16_t*>(d->hs[0]); a.ldh = d->ldh;
+  a.h0 = reinterpret_cast<const bf16_t*>(d->h0[0]); a.ldh0 = d->ldh0;
+  a.dh_last = d->dh_last[0];
+  a.dy = d->dy; a.dy_ld = d->dy_ld;
+  a.lengths = d->lengths;
+  a.dG = reinterpret_cast<bf16_t*>(d->dG[0]); a.ldg = d->ldg;
+  a.T = d->T; a.B = d->B;
+  constexpr size_t lds = (size_t)(H / 16) * (H / 32) * 1024 + 2 * (4 * GR_RPL) * GRB_LDG * sizeof(bf16_t);
+  static bool attr_set = false;
+  if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+  hipLaunchKernelGGL((gru_rowres_bwd_kernel<H>), dim3((d->B + 4 * GR_RPL - 1) / (4 * GR_RPL)), dim3(512), lds, st, a);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
