@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) 
 // Gate slots, masks and saved tensors exactly as lstm_step_fwd_kernel's GRU branch (rnn.hip): slots [r | z | W_in x + b_in | W_hn h + b_hn],
 // a finished row keeps its state and emits zeros.
 constexpr int GR_ROWS = 16;        // MFMA rows of the A tile
-constexpr int GR_RPL = 2;          // real batch rows per lane (of its 4 accumulator rows): 8 batch rows per workgroup
+constexpr int GR_RPL = 1;          // real batch rows per lane (of its 4 accumulator rows): 4 batch rows per workgroup (B = 1024: one workgroup per CU)
 __device__ __forceinline__ bf16_t f2bf_t(float f) { bf16_t r; r.x = f2bf(f); return r; }
 // the bf16 step kernels' activation forms (rnn.hip act_sigmoid<bf16_t> / act_tanh<bf16_t>): same numbers on either schedule
 __device__ __forceinline__ float act_sigmoid_bf(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -408,11 +408,15 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
 #pragma unroll
     for (int j = 0; j < UT; ++j) hst[i][j] = p.h0 ? bf2f(p.h0[(long)rc * p.ldh0 + u0 + 16 * j].x) : 0.f;
   }
-  auto token = [&](int i, int t) -> int {                     // clamped table row of (row i, step t)
-    const int rc = (rbase + i < B) ? rbase + i : B - 1;
+  // token ids of the workgroup's rows for every step, clamped, in LDS (a global load inside the time loop would sit in the same in-order
+  // memory queue as the step's stores: waiting for it waits for their acknowledgements)
+  int* tok_s = reinterpret_cast<int*>(smem + WN_BYTES + 2 * GR_ROWS * LDA * 2 + 4 * H * 4);      // [4 RPL][T]
+  for (int i = tid; i < 4 * RPL * T; i += 512) {
+    const int r = i / T, t = i - r * T;
+    const int rc = (r0 + r < B) ? r0 + r : B - 1;
     const long id = p.idx[(long)rc * p.idx_ld + t];
-    return (int)(id < 0 ? 0 : (id >= p.tbl_rows ? p.tbl_rows - 1 : id));
-  };
+    tok_s[i] = (int)(id < 0 ? 0 : (id >= p.tbl_rows ? p.tbl_rows - 1 : id));
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): the weight registers are complete before the time loop (see lstm_rowres_fwd_kernel)
   for (int i = tid; i < 2 * GR_ROWS * LDA / 2; i += 512) reinterpret_cast<uint32_t*>(&abuf[0][0][0])[i] = 0u;      // padding rows stay zero
   __syncthreads();
@@ -420,30 +424,27 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
   for (int i = 0; i < RPL; ++i)
 #pragma unroll
     for (int j = 0; j < UT; ++j) abuf[0][4 * lq + i][u0 + 16 * j] = f2bf_t(hst[i][j]);      // A buffer of step 0: h_0
-  int tok[RPL];
-#pragma unroll
-  for (int i = 0; i < RPL; ++i) tok[i] = token(i, 0);
-  __syncthreads();
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-  const uint32_t a_lane = lds0 + (uint32_t)WN_BYTES + (uint32_t)(lc * LDA * 2 + lq * 16);
-  const uint32_t wn_lane = lds0 + (uint32_t)((2 * wave * KBLK * 64 + lane) * 16);
-  for (int t = 0; t < T; ++t) {
-    const int cur = t & 1, nxt = cur ^ 1;
-    // this step's table rows (requested first: they are needed only behind the MFMAs) and the next step's token ids
-    float gx[RPL][3][UT];
+  typedef float Gx[RPL][3][UT];
+  auto load_gx = [&](int t, Gx& g) {                          // table rows of step t for the lane's rows / units
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
-      const float* tr = p.tbl + (long)tok[i] * 4 * H + u0;
+      const float* tr = p.tbl + (long)tok_s[(RPL * lq + i) * T + t] * 4 * H + u0;
 #pragma unroll
       for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int j = 0; j < UT; ++j) gx[i][s][j] = tr[s * H + 16 * j];
+        for (int j = 0; j < UT; ++j) g[i][s][j] = tr[s * H + 16 * j];
     }
-    if (t + 1 < T) {
-#pragma unroll
-      for (int i = 0; i < RPL; ++i) tok[i] = token(i, t + 1);
-    }
-    // ---- gh = h_{t-1} . W_hh^T for the wave's 32 units x 3 gates; A and W_hn fragments stream through two register sets
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const uint32_t a_lane = lds0 + (uint32_t)WN_BYTES + (uint32_t)(lc * LDA * 2 + lq * 16);
+  const uint32_t wn_lane = lds0 + (uint32_t)((2 * wave * KBLK * 64 + lane) * 16);
+  const uint32_t hs_ts = (uint32_t)B * (uint32_t)p.ldh, g_ts = (uint32_t)B * 4u * H;      // elements per time step
+  // one time step: `gx` holds this step's table rows (requested a step ago), `gxn` receives the next step's -- requested FIRST, in front of
+  // this step's stores, so that the wait for them next step never includes a store acknowledgement
+  auto step = [&](int t, Gx& gx, Gx& gxn) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    if (t + 1 < T) load_gx(t + 1, gxn);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[3][UT];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -452,7 +453,6 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
     const uint32_t ab = a_lane + (uint32_t)(cur * GR_ROWS * LDA * 2);
     u32x4 af[2], wn[2][UT];
     gru_frag_step<0, KBLK, UT>(af, wn, ab, wn_lane, wf, acc);
-    // ---- cell update: RPL rows of two units per lane
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const int row = rbase + i;
@@ -471,16 +471,24 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
         const float hseq = valid ? hn : 0.f;
         abuf[nxt][4 * lq + i][u] = f2bf_t(hst[i][j]);
         if (row < B) {
-          p.hs[((long)t * B + row) * p.ldh + u] = f2bf_t(hseq);
+          // 32-bit element offsets from uniform bases (host: both tensors < 2^31 elements): scalar base + one offset register per store
+          p.hs[(uint32_t)t * hs_ts + (uint32_t)row * (uint32_t)p.ldh + (uint32_t)u] = f2bf_t(hseq);
           if (p.gates) {
-            bf16_t* g4 = p.gates + ((long)t * B + row) * 4 * H + u;
-            g4[0] = f2bf_t(gr); g4[H] = f2bf_t(gz); g4[2 * H] = f2bf_t(gn); g4[3 * H] = f2bf_t(ph);
+            const uint32_t go = (uint32_t)t * g_ts + (uint32_t)row * 4u * H + (uint32_t)u;
+            p.gates[go] = f2bf_t(gr); p.gates[go + H] = f2bf_t(gz); p.gates[go + 2 * H] = f2bf_t(gn); p.gates[go + 3 * H] = f2bf_t(ph);
           }
         }
       }
     }
     wait_lgkmcnt<0>();                                        // my LDS writes of h_t are done
     ws_barrier();                                             // (no vmcnt wait: the stores of this step stay in flight)
+  };
+  __syncthreads();
+  Gx gxa, gxb;
+  load_gx(0, gxa);
+  for (int t = 0; t < T; t += 2) {                            // two steps per iteration: the register sets swap roles, nothing is copied
+    step(t, gxa, gxb);
+    if (t + 1 < T) step(t + 1, gxb, gxa);
   }
 #pragma unroll
   for (int i = 0; i < RPL; ++i) {
@@ -501,7 +509,6 @@ struct GruRowB {
   const bf16_t* hs; long ldh;        // [T][B][ldh] forward outputs (h_{t-1} of step t = hs[t-1])
   const bf16_t* h0; long ldh0;       // [B][ldh0] or nullptr
   const float* dh_last;              // [B][H] gradient w.r.t. the final state, or nullptr
-  const float* dy; long dy_ld;       // [T*B][dy_ld] gradient w.r.t. the output sequence, or nullptr
   const int* lengths;
   bf16_t* dG; long ldg;              // out [T][B][ldg], 4 slots
   int T, B;
@@ -582,17 +589,17 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
       }
     }
   };
-  Ops cur_ops;
-  load_ops(T - 1, cur_ops);
   __syncthreads();
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const int rr = ((lc & 3) < RPL) ? (lc >> 2) * RPL + (lc & 3) : 0;      // MFMA tile row lc -> real row (padding rows alias row 0: their results are unused)
   const uint32_t a_lane = lds0 + (uint32_t)WL_BYTES + (uint32_t)(rr * LDG * 2 + lq * 16);
   const uint32_t wl_lane = lds0 + (uint32_t)((2 * wave * KBH * 64 + lane) * 16);
-  for (int t = T - 1; t >= 0; --t) {
-    const int cur = (T - 1 - t) & 1, nxt = cur ^ 1;
-    Ops nxt_ops;
-    if (t > 0) load_ops(t - 1, nxt_ops);                      // next step's operands: in flight under this step
+  // one time step: `o` holds this step's operands (requested a step ago), `on` receives the next step's -- requested first, in front of this
+  // step's stores (the memory queue is in order: a load behind a store cannot be waited for without the store's acknowledgement)
+  auto step = [&](int t, int k, Ops& o, Ops& on) {
+    const int cur = k & 1, nxt = cur ^ 1;
+    if (t > 0) load_ops(t - 1, on);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- dh_t += dG_{t+1}[r | z | n*r] . W_hh  (zero at t = T - 1)
     f32x4 acc[UT];
 #pragma unroll
@@ -608,12 +615,11 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
 #pragma unroll
       for (int j = 0; j < UT; ++j) {
         const int u = u0 + 16 * j;
-        float d = dh[i][j] + acc[j][i];
+        const float d = dh[i][j] + acc[j][i];
         float dpr = 0.f, dpz = 0.f, dpn = 0.f, dpnr = 0.f, carry = d;
         if (valid) {
-          if (p.dy && row < B) d += p.dy[((long)t * B + row) * p.dy_ld + u];
-          const float gr = bf2f(cur_ops.g[i][j][0]), gz = bf2f(cur_ops.g[i][j][1]), gn = bf2f(cur_ops.g[i][j][2]), nh = bf2f(cur_ops.g[i][j][3]);
-          const float hp = bf2f(cur_ops.hp[i][j]);
+          const float gr = bf2f(o.g[i][j][0]), gz = bf2f(o.g[i][j][1]), gn = bf2f(o.g[i][j][2]), nh = bf2f(o.g[i][j][3]);
+          const float hp = bf2f(o.hp[i][j]);
           const float dn = d * (1.f - gz);
           const float dz = d * (hp - gn);
           dpn = dn * (1.f - gn * gn);
@@ -632,9 +638,14 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
         }
       }
     }
-    if (t > 0) cur_ops = nxt_ops;
     wait_lgkmcnt<0>();
     ws_barrier();
+  };
+  Ops oa, ob;
+  load_ops(T - 1, oa);
+  for (int t = T - 1, k = 0; t >= 0; t -= 2, k += 2) {        // two steps per iteration: the operand sets swap roles, nothing is copied
+    step(t, k, oa, ob);
+    if (t >= 1) step(t - 1, k + 1, ob, oa);
   }
 }
 
@@ -719,6 +730,7 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if (d->cell != MVAE_CELL_GRU || d->dtype != MVAE_BF16 || d->layers != 1 || d->H != H || d->x0 || d->add0 || !d->add_table || !d->add_index)
     return MVAE_ERR_UNSUPPORTED;
   if (d->drop_p > 0.f || !d->hs[0] || !d->cstate[0] || d->T < 1) return MVAE_ERR_UNSUPPORTED;
+  if ((long)d->T * d->B * 4 * H >= (1L << 31) || (long)d->T * d->B * d->ldh >= (1L << 31)) return MVAE_ERR_UNSUPPORTED;      // 32-bit element offsets in the kernel
   if (d->ldw_hh[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hh[0]) & 15)) return MVAE_ERR_UNSUPPORTED;
   GruRowF a;
   a.w_hh = reinterpret_cast<const bf16_t*>(d->w_hh[0]); a.ldw = d->ldw_hh[0];
@@ -730,7 +742,8 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   a.gates = reinterpret_cast<bf16_t*>(d->gates[0]);
   a.hstate = d->cstate[0];
   a.T = d->T; a.B = d->B;
-  constexpr size_t lds = (size_t)(H / 16) * (H / 32) * 1024 + 2 * GR_ROWS * (H + 8) * sizeof(bf16_t) + 4 * H * sizeof(float);      // W_hn fragments + the double-buffered A rows + bias
+  const size_t lds = (size_t)(H / 16) * (H / 32) * 1024 + 2 * GR_ROWS * (H + 8) * sizeof(bf16_t) + 4 * H * sizeof(float) + (size_t)4 * GR_RPL * d->T * sizeof(int);      // W_hn fragments + the double-buffered A rows + bias + token ids
+  if (lds > 160 * 1024) return MVAE_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
   hipLaunchKernelGGL((gru_rowres_fwd_kernel<H>), dim3((d->B + 4 * GR_RPL - 1) / (4 * GR_RPL)), dim3(512), lds, st, a);
@@ -741,7 +754,7 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
 // backward of the same stack: one launch; the weight / bias / table gradients stay with the caller's GEMMs over dG
 int rnn_gru_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   constexpr int H = 256;
-  if (d->cell != MVAE_CELL_GRU || d->dtype != MVAE_BF16 || d->layers != 1 || d->H != H || d->dy_a || d->drop_p > 0.f) return MVAE_ERR_UNSUPPORTED;
+  if (d->cell != MVAE_CELL_GRU || d->dtype != MVAE_BF16 || d->layers != 1 || d->H != H || d->dy || d->dy_a || d->drop_p > 0.f) return MVAE_ERR_UNSUPPORTED;      // (a gradient through the output sequence: the wavefront schedule)
   if (d->dh0[0] || !d->gates[0] || !d->hs[0] || !d->dG[0] || !d->w_hhT[0] || d->T < 1) return MVAE_ERR_UNSUPPORTED;
   if (d->ldw_hhT[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hhT[0]) & 15) || d->ldg < 4L * H) return MVAE_ERR_UNSUPPORTED;
   GruRowB a;
@@ -750,7 +763,6 @@ int rnn_gru_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   a.hs = reinterpret_cast<const bf16_t*>(d->hs[0]); a.ldh = d->ldh;
   a.h0 = reinterpret_cast<const bf16_t*>(d->h0[0]); a.ldh0 = d->ldh0;
   a.dh_last = d->dh_last[0];
-  a.dy = d->dy; a.dy_ld = d->dy_ld;
   a.lengths = d->lengths;
   a.dG = reinterpret_cast<bf16_t*>(d->dG[0]); a.ldg = d->ldg;
   a.T = d->T; a.B = d->B;
