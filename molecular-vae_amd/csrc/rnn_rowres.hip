@@ -341,6 +341,27 @@ struct GruRowF {
   int T, B;
 };
 
+// Loads of the time loops as inline asm: the compiler's wait-count pass loses the exact queue state at a loop's back edge and drains the
+// whole queue -- this step's table rows AND the previous step's stores (their acknowledgements: ~1 us) -- where a counted wait for the loads
+// alone is enough.  The memory queue is in order, so "everything older than the newest N operations has completed" is exact once the number
+// of stores per step is fixed (host: B a multiple of the rows per workgroup; template GATES).
+template <int OFF> __device__ __forceinline__ float gload_f32(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF> __device__ __forceinline__ uint32_t gload_u16(const bf16_t* p) {
+  uint32_t v;
+  asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+  return v;
+}
+template <int NL, int NS> __device__ __forceinline__ void wait_vm_case(bool next_issued, bool prev_stores) {
+  // operands of the current step are older than: this step's NL loads (if issued) and the previous step's NS stores (if any)
+  __builtin_amdgcn_sched_barrier(0);
+  if (next_issued) { if (prev_stores) wait_vmcnt<NL + NS>(); else wait_vmcnt<NL>(); }
+  else { if (prev_stores) wait_vmcnt<NS>(); else wait_vmcnt<0>(); }
+  __builtin_amdgcn_sched_barrier(0);
+}
 // K loop of one step: fragment set kb & 1 holds the A fragment (h_{t-1}) and the W_hn fragments of K-block kb; the reads of block kb + 1
 // are in flight under the MFMAs of block kb (three ds_read_b128 per block: the counted wait lets exactly those three stay outstanding)
 template <int KB_, int KBLK, int UT> struct GruFrag {
@@ -372,7 +393,7 @@ __device__ __forceinline__ void gru_frag_step(u32x4 (&af)[2], u32x4 (&wn)[2][UT]
   GruFrag<0, KBLK, UT>::run(af, wn, ab, wnb, wf, acc);
 }
 
-template <int H>
+template <int H, bool GATES>
 __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
   static_assert(H == 256, "8 waves x 32 hidden units");
   constexpr int KBLK = H / 32, LDA = H + 8, UT = 2, RPL = GR_RPL;          // A rows padded by 16 bytes: the 16 rows of a fragment read start on different banks
@@ -425,15 +446,13 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
 #pragma unroll
     for (int j = 0; j < UT; ++j) abuf[0][4 * lq + i][u0 + 16 * j] = f2bf_t(hst[i][j]);      // A buffer of step 0: h_0
   typedef float Gx[RPL][3][UT];
-  auto load_gx = [&](int t, Gx& g) {                          // table rows of step t for the lane's rows / units
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-      const float* tr = p.tbl + (long)tok_s[(RPL * lq + i) * T + t] * 4 * H + u0;
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int j = 0; j < UT; ++j) g[i][s][j] = tr[s * H + 16 * j];
-    }
+  static_assert(RPL == 1 && UT == 2, "load / store counts of the counted waits below");
+  constexpr int NLD = 6, NST = GATES ? 10 : 2;                // vector loads / stores of one step
+  auto load_gx = [&](int t, Gx& g) {                          // table rows of step t for the lane's row / units (asm: see gload_f32)
+    const float* tr = p.tbl + (long)tok_s[lq * T + t] * 4 * H + u0;
+    g[0][0][0] = gload_f32<0>(tr); g[0][0][1] = gload_f32<64>(tr);
+    g[0][1][0] = gload_f32<4 * H>(tr); g[0][1][1] = gload_f32<4 * H + 64>(tr);
+    g[0][2][0] = gload_f32<8 * H>(tr); g[0][2][1] = gload_f32<8 * H + 64>(tr);
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t a_lane = lds0 + (uint32_t)WN_BYTES + (uint32_t)(lc * LDA * 2 + lq * 16);
@@ -453,6 +472,9 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
     const uint32_t ab = a_lane + (uint32_t)(cur * GR_ROWS * LDA * 2);
     u32x4 af[2], wn[2][UT];
     gru_frag_step<0, KBLK, UT>(af, wn, ab, wn_lane, wf, acc);
+    wait_vm_case<NLD, NST>(t + 1 < T, t > 0);                 // this step's table rows have arrived
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(gx[i][0][0]), "+v"(gx[i][0][1]), "+v"(gx[i][1][0]), "+v"(gx[i][1][1]), "+v"(gx[i][2][0]), "+v"(gx[i][2][1]));
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const int row = rbase + i;
@@ -470,13 +492,12 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
         hst[i][j] = valid ? hn : hst[i][j];
         const float hseq = valid ? hn : 0.f;
         abuf[nxt][4 * lq + i][u] = f2bf_t(hst[i][j]);
-        if (row < B) {
-          // 32-bit element offsets from uniform bases (host: both tensors < 2^31 elements): scalar base + one offset register per store
-          p.hs[(uint32_t)t * hs_ts + (uint32_t)row * (uint32_t)p.ldh + (uint32_t)u] = f2bf_t(hseq);
-          if (p.gates) {
-            const uint32_t go = (uint32_t)t * g_ts + (uint32_t)row * 4u * H + (uint32_t)u;
-            p.gates[go] = f2bf_t(gr); p.gates[go + H] = f2bf_t(gz); p.gates[go + 2 * H] = f2bf_t(gn); p.gates[go + 3 * H] = f2bf_t(ph);
-          }
+        // (host: B is a multiple of the 4 rows of a workgroup -- every row is real, every store happens: the counted waits rely on it)
+        // 32-bit element offsets from uniform bases (host: both tensors < 2^31 elements): scalar base + one offset register per store
+        p.hs[(uint32_t)t * hs_ts + (uint32_t)row * (uint32_t)p.ldh + (uint32_t)u] = f2bf_t(hseq);
+        if constexpr (GATES) {
+          const uint32_t go = (uint32_t)t * g_ts + (uint32_t)row * 4u * H + (uint32_t)u;
+          p.gates[go] = f2bf_t(gr); p.gates[go + H] = f2bf_t(gz); p.gates[go + 2 * H] = f2bf_t(gn); p.gates[go + 3 * H] = f2bf_t(ph);
         }
       }
     }
@@ -485,6 +506,7 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
   };
   __syncthreads();
   Gx gxa, gxb;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the counted waits start from an empty queue
   load_gx(0, gxa);
   for (int t = 0; t < T; t += 2) {                            // two steps per iteration: the register sets swap roles, nothing is copied
     step(t, gxa, gxb);
@@ -573,21 +595,20 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): the weight registers are complete before the time loop
   for (int i = tid; i < 2 * NROW * LDG / 2; i += 512) reinterpret_cast<uint32_t*>(&gbuf[0][0][0])[i] = 0u;      // dG_T = 0
-  // operands of step t: saved gates of (row i, unit tile j) and h_{t-1}
-  struct Ops { uint16_t g[RPL][UT][4]; uint16_t hp[RPL][UT]; };
+  // operands of step t: saved gates of the lane's row / two unit tiles and h_{t-1}.  Ten asm loads per step, always (see gload_f32): with no
+  // initial state the t = 0 read goes to the gates row instead and is replaced by zero
+  static_assert(RPL == 1 && UT == 2, "load / store counts of the counted waits below");
+  constexpr int NLD = 10, NST = 8;
+  struct Ops { uint32_t g[UT][4]; uint32_t hp[UT]; };
+  const int rc0 = (rbase < B) ? rbase : B - 1;
   auto load_ops = [&](int t, Ops& o) {
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-      const int rc = (rbase + i < B) ? rbase + i : B - 1;
-      const bf16_t* g4 = p.gates + ((long)t * B + rc) * 4 * H + u0;
-      const bf16_t* hp = (t > 0) ? p.hs + ((long)(t - 1) * B + rc) * p.ldh + u0 : (p.h0 ? p.h0 + (long)rc * p.ldh0 + u0 : nullptr);
-#pragma unroll
-      for (int j = 0; j < UT; ++j) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) o.g[i][j][s] = g4[s * H + 16 * j].x;
-        o.hp[i][j] = hp ? hp[16 * j].x : (uint16_t)0;
-      }
-    }
+    const bf16_t* g4 = p.gates + ((long)t * B + rc0) * 4 * H + u0;
+    const bf16_t* hp = (t > 0) ? p.hs + ((long)(t - 1) * B + rc0) * p.ldh + u0 : (p.h0 ? p.h0 + (long)rc0 * p.ldh0 + u0 : g4);
+    o.g[0][0] = gload_u16<0>(g4); o.g[1][0] = gload_u16<32>(g4);
+    o.g[0][1] = gload_u16<2 * H>(g4); o.g[1][1] = gload_u16<2 * H + 32>(g4);
+    o.g[0][2] = gload_u16<4 * H>(g4); o.g[1][2] = gload_u16<4 * H + 32>(g4);
+    o.g[0][3] = gload_u16<6 * H>(g4); o.g[1][3] = gload_u16<6 * H + 32>(g4);
+    o.hp[0] = gload_u16<0>(hp); o.hp[1] = gload_u16<32>(hp);
   };
   __syncthreads();
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
@@ -608,6 +629,10 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
     u32x4 af[2], wl[2][UT];
     af[0] = lds_read128<0>(ab);
     GruFragB<0, NREG, NK, UT>::run(af, wl, ab, wl_lane, wf, acc);
+    wait_vm_case<NLD, NST>(t > 0, k > 0);                     // this step's operands have arrived
+#pragma unroll
+    for (int j = 0; j < UT; ++j) asm volatile("" : "+v"(o.g[j][0]), "+v"(o.g[j][1]), "+v"(o.g[j][2]), "+v"(o.g[j][3]), "+v"(o.hp[j]));
+    const bool has_hp = t > 0 || p.h0 != nullptr;
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const int row = rbase + i;
@@ -618,8 +643,8 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
         const float d = dh[i][j] + acc[j][i];
         float dpr = 0.f, dpz = 0.f, dpn = 0.f, dpnr = 0.f, carry = d;
         if (valid) {
-          const float gr = bf2f(o.g[i][j][0]), gz = bf2f(o.g[i][j][1]), gn = bf2f(o.g[i][j][2]), nh = bf2f(o.g[i][j][3]);
-          const float hp = bf2f(o.hp[i][j]);
+          const float gr = bf2f((uint16_t)o.g[j][0]), gz = bf2f((uint16_t)o.g[j][1]), gn = bf2f((uint16_t)o.g[j][2]), nh = bf2f((uint16_t)o.g[j][3]);
+          const float hp = has_hp ? bf2f((uint16_t)o.hp[j]) : 0.f;
           const float dn = d * (1.f - gz);
           const float dz = d * (hp - gn);
           dpn = dn * (1.f - gn * gn);
@@ -632,7 +657,7 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
         const bf16_t br = f2bf_t(dpr), bz = f2bf_t(dpz), bnr = f2bf_t(dpnr);
         bf16_t* gl = &gbuf[nxt][RPL * lq + i][u];
         gl[0] = br; gl[H] = bz; gl[2 * H] = bnr;
-        if (row < B) {
+        {     // (host: B is a multiple of the 4 rows of a workgroup: every store happens -- the counted waits rely on it)
           bf16_t* d4 = p.dG + ((long)t * B + row) * p.ldg + u;
           d4[0] = br; d4[H] = bz; d4[2 * H] = f2bf_t(dpn); d4[3 * H] = bnr;
         }
@@ -642,6 +667,7 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
     ws_barrier();
   };
   Ops oa, ob;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the counted waits start from an empty queue
   load_ops(T - 1, oa);
   for (int t = T - 1, k = 0; t >= 0; t -= 2, k += 2) {        // two steps per iteration: the operand sets swap roles, nothing is copied
     step(t, k, oa, ob);
@@ -729,7 +755,7 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   constexpr int H = 256;
   if (d->cell != MVAE_CELL_GRU || d->dtype != MVAE_BF16 || d->layers != 1 || d->H != H || d->x0 || d->add0 || !d->add_table || !d->add_index)
     return MVAE_ERR_UNSUPPORTED;
-  if (d->drop_p > 0.f || !d->hs[0] || !d->cstate[0] || d->T < 1) return MVAE_ERR_UNSUPPORTED;
+  if (d->drop_p > 0.f || !d->hs[0] || !d->cstate[0] || d->T < 1 || d->B % (4 * GR_RPL)) return MVAE_ERR_UNSUPPORTED;      // whole workgroups of rows (ragged batches: the wavefront schedule)
   if ((long)d->T * d->B * 4 * H >= (1L << 31) || (long)d->T * d->B * d->ldh >= (1L << 31)) return MVAE_ERR_UNSUPPORTED;      // 32-bit element offsets in the kernel
   if (d->ldw_hh[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hh[0]) & 15)) return MVAE_ERR_UNSUPPORTED;
   GruRowF a;
@@ -745,8 +771,13 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   const size_t lds = (size_t)(H / 16) * (H / 32) * 1024 + 2 * GR_ROWS * (H + 8) * sizeof(bf16_t) + 4 * H * sizeof(float) + (size_t)4 * GR_RPL * d->T * sizeof(int);      // W_hn fragments + the double-buffered A rows + bias + token ids
   if (lds > 160 * 1024) return MVAE_ERR_UNSUPPORTED;
   static bool attr_set = false;
-  if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-  hipLaunchKernelGGL((gru_rowres_fwd_kernel<H>), dim3((d->B + 4 * GR_RPL - 1) / (4 * GR_RPL)), dim3(512), lds, st, a);
+  if (!attr_set) {
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_fwd_kernel<H, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_fwd_kernel<H, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (a.gates) hipLaunchKernelGGL((gru_rowres_fwd_kernel<H, true>), dim3(d->B / (4 * GR_RPL)), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((gru_rowres_fwd_kernel<H, false>), dim3(d->B / (4 * GR_RPL)), dim3(512), lds, st, a);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
@@ -755,7 +786,7 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
 int rnn_gru_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   constexpr int H = 256;
   if (d->cell != MVAE_CELL_GRU || d->dtype != MVAE_BF16 || d->layers != 1 || d->H != H || d->dy || d->dy_a || d->drop_p > 0.f) return MVAE_ERR_UNSUPPORTED;      // (a gradient through the output sequence: the wavefront schedule)
-  if (d->dh0[0] || !d->gates[0] || !d->hs[0] || !d->dG[0] || !d->w_hhT[0] || d->T < 1) return MVAE_ERR_UNSUPPORTED;
+  if (d->dh0[0] || !d->gates[0] || !d->hs[0] || !d->dG[0] || !d->w_hhT[0] || d->T < 1 || d->B % (4 * GR_RPL)) return MVAE_ERR_UNSUPPORTED;
   if (d->ldw_hhT[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hhT[0]) & 15) || d->ldg < 4L * H) return MVAE_ERR_UNSUPPORTED;
   GruRowB a;
   a.w_hhT = reinterpret_cast<const bf16_t*>(d->w_hhT[0]); a.ldwT = d->ldw_hhT[0];
@@ -769,7 +800,7 @@ int rnn_gru_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   constexpr size_t lds = (size_t)(H / 16) * (H / 32) * 1024 + 2 * (4 * GR_RPL) * GRB_LDG * sizeof(bf16_t);
   static bool attr_set = false;
   if (!attr_set) { MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rowres_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-  hipLaunchKernelGGL((gru_rowres_bwd_kernel<H>), dim3((d->B + 4 * GR_RPL - 1) / (4 * GR_RPL)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gru_rowres_bwd_kernel<H>), dim3(d->B / (4 * GR_RPL)), dim3(512), lds, st, a);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
