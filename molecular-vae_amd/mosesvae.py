@@ -413,8 +413,16 @@ class _MosesFn(torch.autograd.Function):
             ops.onehot_tb(x_pad, onehot, B, T, V)
         dE = W("dE", (V, V))
 
-        def dec_weight_grads():
+        def dec_bias_grads():
+            # column sums of dG (bandwidth-bound passes over [T*B, 4H]): on the MAIN stream behind the encoder's backward, beside the side
+            # stream's compute-bound weight-gradient GEMMs -- the side stream is the longer of the two chains since the encoder's backward is one launch
             s4 = W("dec_s4", (4 * Hd,))
+            for l in range(NL):
+                ops.colsum_t(dG_d[l].view(TB, ldg_d), TB, 4 * Hd, s4, ldx=ldg_d)
+                grads[f"decoder_rnn.bias_ih_l{l}"].copy_(s4[:3 * Hd])
+                grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
+
+        def dec_weight_grads():
             for l in range(NL):
                 a = dG_d[l].view(TB, ldg_d)
                 hprev = hsx_d[l][:T].reshape(TB, ldh_d)                  # h_{t-1} for every t (slot 0 = h_0)
@@ -424,9 +432,6 @@ class _MosesFn(torch.autograd.Function):
                 if l > 0:                                                 # the layer's input: the output of layer l-1 (after its dropout in train mode)
                     xin = hd[l - 1].view(TB, ldh_d) if hd is not None else hsx_d[l - 1][1:].reshape(TB, ldh_d)
                     _kmajor_gemm(ws, "dwih", a, ldg_d, 3 * Hd, xin, ldh_d, Hd, TB, grads[f"decoder_rnn.weight_ih_l{l}"], dev)
-                ops.colsum_t(a, TB, 4 * Hd, s4, ldx=ldg_d)
-                grads[f"decoder_rnn.bias_ih_l{l}"].copy_(s4[:3 * Hd])
-                grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
             # layer-0 input = [emb(x_t), z]: table gradient for the embedding part (the z part is on the path to the encoder: main stream)
             dtbl3 = W("dec_dtbl3", (V, 3 * Hd))
             if onehot is not None:
@@ -505,6 +510,7 @@ class _MosesFn(torch.autograd.Function):
         dE2 = W("dE2", (V, V)); ops.gemm_nt(etbl3, pe["WxT"], dE2, V, V, 3 * Hq)
         etblT = W("enc_dtblT", (3 * Hq, Vp)); ops.cast_transpose(etbl3, V, 3 * Hq, dstT=etblT)
         ops.gemm_nt(etblT, P["ET_p"], grads["encoder_rnn.weight_ih_l0"], 3 * Hq, V, Vp)
+        dec_bias_grads()
         if side_done is not None:
             torch.cuda.current_stream().wait_event(side_done)        # the decoder's parameter gradients (and dE) from the side stream
         ge = grads["x_emb.weight"]; torch.add(dE, dE2, out=ge)

@@ -73,7 +73,15 @@ def host_us(fn, launches):
 
 nl = T + NL - 1
 per_t = 2 * B * G4 * (H + 3 * 2 * H)
-if "host" in which:
+if "hostn" in which:
+    import time
+    for n in (1, 2, 4, 8, 16):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            bwd()
+        t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(f"bwd x{n}: enqueue {1e6 * (t1 - t0) / (n * nl):.2f} us/launch, GPU {1e6 * (t2 - t0) / (n * nl):.2f} us/launch ({n * nl} launches queued back to back)")
+if "host" in which.split(","):
     print(f"host enqueue: fwd {host_us(fwd, nl):.2f} us/launch, bwd {host_us(bwd, nl):.2f} us/launch (bwd split forms: two launches per diagonal)")
 if "fwd" in which:
     ms = timeit(fwd)
