@@ -20,6 +20,10 @@
 namespace {
 
 constexpr int RR_ROWS = 4;
+// Barrier of the time loops: this wave's LDS traffic has completed (lgkmcnt), then s_barrier -- WITHOUT the vmcnt(0) that __syncthreads()
+// carries (its workgroup-scope fence): nothing a step writes to global memory is read by another wave of the pass, and with it every barrier
+// waited for the write acknowledgements of the step's hs / cs / gates (dG / dx) stores, twice per time step.
+__device__ __forceinline__ void rr_barrier() { wait_lgkmcnt<0>(); ws_barrier(); }
 
 template <int KK, int KW, int NG> struct RowMma {
   static __device__ __forceinline__ void run(const float (&areg)[(KW + 15) / 16], const float (&W)[NG][KW], f32x4 (&C)[NG]) {
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
 #pragma unroll
         for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     }
-    __syncthreads();
+    rr_barrier();
     // ---- gate phase.  x_{t+1} (requested before the MFMA phase) goes into the next A buffer first: behind this step's stores the wait
     // for it would also wait for their write acknowledgements
     if (HASX && tid < RR_ROWS * (H / 4)) *reinterpret_cast<float4*>(&abuf[nxt][xr][xc]) = xpre;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
       }
     }
     if (p.add && t + 1 < T) load_add(t + 1);
-    __syncthreads();
+    rr_barrier();
   }
 }
 
@@ -270,7 +274,7 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
         d4[0] = di; d4[H] = df; d4[2 * H] = dg; d4[3 * H] = dO;
       }
     }
-    __syncthreads();
+    rr_barrier();
     // ---- MFMA phase: wave w contracts gate w
     if (wave < 4) {
       float areg[NA];
@@ -288,7 +292,7 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
 #pragma unroll
         for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     }
-    __syncthreads();
+    rr_barrier();
   }
   if (HASX) {                                                       // input gradient of step 0
 #pragma unroll
