@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) 
 // =====================================================================================================================
 // Row-resident GRU for ONE-layer bf16 stacks of H = 256 whose input projection is a token table (the MOSES encoder: GRU(V -> 256),
 // mosesvae.py:142-156 with the embedding folded into tbl[V][4H]).  The wavefront schedule pays one launch per time step for
-// 0.4 GFLOP (8 us each, 59 + 59 launches of a 6 ms step).  Here a workgroup of 8 waves owns 16 batch rows for the whole sequence:
+// 0.4 GFLOP (8 us each, 59 + 59 launches of a 6 ms step).  Here a workgroup of 8 waves owns 4 batch rows (one per accumulator-row group of the 16-row MFMA tile; the other rows
+// are zero padding: the MFMA rate is not what a step waits for, registers per lane are) for the whole sequence:
 //   * W_hh (768 x 256 bf16 = 393 KB) lives in REGISTERS for the whole pass: wave w holds, for hidden units 32 w .. 32 w + 31, the rows of
 //     its r and z gates as B fragments of v_mfma_f32_16x16x32_bf16 (2 gates x 2 unit tiles x 8 K-blocks x 4 VGPRs = 128 VGPRs); the n gate's
 //     fragments (W_hn, 128 KB) sit in LDS in fragment order and stream through registers with the A fragments;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
   bf16_t (*abuf)[GR_ROWS][LDA] = reinterpret_cast<bf16_t (*)[GR_ROWS][LDA]>(smem + WN_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
   const int r0 = blockIdx.x * (4 * RPL), B = p.B, T = p.T;   // RPL of the 4 accumulator rows of a lane are real batch rows (registers: gx / state per row)
-  const int u0 = 32 * wave + lc;                              // this lane's hidden units: u0 and u0 + 16; its batch rows: r0 + 4 lq + i
+  const int u0 = 32 * wave + lc;                              // this lane's hidden units: u0 and u0 + 16; its batch row: r0 + lq
   // ---- weights: fragment (gate s, unit tile j, K-block kb) = W[slot_s * H + u0 + 16 j][32 kb + 8 lq .. + 8].
   // r and z stay in registers (128 VGPRs); the n gate's go to LDS in fragment order (a wave reads back only what it wrote itself)
   uint4 wf[2][UT][KBLK];
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
   }
 }
 
-// ---- backward of the same stack.  Walking t = T-1 .. 0 a workgroup keeps, for its 8 batch rows: the carried gradient dh in registers (fp32),
+// ---- backward of the same stack.  Walking t = T-1 .. 0 a workgroup keeps, for its 4 batch rows: the carried gradient dh in registers (fp32),
 // dG_{t+1}[r | z | n*r] as bf16 in LDS (the A operand of  dh_t += dG_{t+1} . W_hh, K = 3H: the zero gate-slot block is never stored), W_hh^T
 // for the wave's 32 output units as B fragments -- K-blocks of the r and z slots in registers (128 VGPRs), of the n*r slot in LDS (128 KB, fragment
 // order).  Gate-derivative math and masks exactly as bwd_cell_finish's GRU branch (rnn.hip); dG[t] goes to global for the weight-gradient GEMMs.
