@@ -350,15 +350,13 @@ struct GruRowF {
 // whole queue -- this step's table rows AND the previous step's stores (their acknowledgements: ~1 us) -- where a counted wait for the loads
 // alone is enough.  The memory queue is in order, so "everything older than the newest N operations has completed" is exact once the number
 // of stores per step is fixed (host: B a multiple of the rows per workgroup; template GATES).
-template <int OFF> __device__ __forceinline__ float gload_f32(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
-  return v;
+// The destination is a read-write operand: the variable keeps ONE register across the asm, so the compiler never has a reason to copy a value
+// that has not arrived yet (as the phi of a conditional or loop-carried "=v" result would: measured the hard way on the f32 LSTM loops).
+template <int OFF> __device__ __forceinline__ void gload_f32(float& dst, const float* p) {
+  asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
-template <int OFF> __device__ __forceinline__ uint32_t gload_u16(const bf16_t* p) {
-  uint32_t v;
-  asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
-  return v;
+template <int OFF> __device__ __forceinline__ void gload_u16(uint32_t& dst, const bf16_t* p) {
+  asm volatile("global_load_ushort %0, %1, off offset:%2" : "+v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
 template <int NL, int NS> __device__ __forceinline__ void wait_vm_case(bool next_issued, bool prev_stores) {
   // operands of the current step are older than: this step's NL loads (if issued) and the previous step's NS stores (if any)
@@ -455,9 +453,9 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
   constexpr int NLD = 6, NST = GATES ? 10 : 2;                // vector loads / stores of one step
   auto load_gx = [&](int t, Gx& g) {                          // table rows of step t for the lane's row / units (asm: see gload_f32)
     const float* tr = p.tbl + (long)tok_s[lq * T + t] * 4 * H + u0;
-    g[0][0][0] = gload_f32<0>(tr); g[0][0][1] = gload_f32<64>(tr);
-    g[0][1][0] = gload_f32<4 * H>(tr); g[0][1][1] = gload_f32<4 * H + 64>(tr);
-    g[0][2][0] = gload_f32<8 * H>(tr); g[0][2][1] = gload_f32<8 * H + 64>(tr);
+    gload_f32<0>(g[0][0][0], tr); gload_f32<64>(g[0][0][1], tr);
+    gload_f32<4 * H>(g[0][1][0], tr); gload_f32<4 * H + 64>(g[0][1][1], tr);
+    gload_f32<8 * H>(g[0][2][0], tr); gload_f32<8 * H + 64>(g[0][2][1], tr);
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t a_lane = lds0 + (uint32_t)WN_BYTES + (uint32_t)(lc * LDA * 2 + lq * 16);
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
     ws_barrier();                                             // (no vmcnt wait: the stores of this step stay in flight)
   };
   __syncthreads();
-  Gx gxa, gxb;
+  Gx gxa = {}, gxb = {};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the counted waits start from an empty queue
   load_gx(0, gxa);
   for (int t = 0; t < T; t += 2) {                            // two steps per iteration: the register sets swap roles, nothing is copied
@@ -609,11 +607,11 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
   auto load_ops = [&](int t, Ops& o) {
     const bf16_t* g4 = p.gates + ((long)t * B + rc0) * 4 * H + u0;
     const bf16_t* hp = (t > 0) ? p.hs + ((long)(t - 1) * B + rc0) * p.ldh + u0 : (p.h0 ? p.h0 + (long)rc0 * p.ldh0 + u0 : g4);
-    o.g[0][0] = gload_u16<0>(g4); o.g[1][0] = gload_u16<32>(g4);
-    o.g[0][1] = gload_u16<2 * H>(g4); o.g[1][1] = gload_u16<2 * H + 32>(g4);
-    o.g[0][2] = gload_u16<4 * H>(g4); o.g[1][2] = gload_u16<4 * H + 32>(g4);
-    o.g[0][3] = gload_u16<6 * H>(g4); o.g[1][3] = gload_u16<6 * H + 32>(g4);
-    o.hp[0] = gload_u16<0>(hp); o.hp[1] = gload_u16<32>(hp);
+    gload_u16<0>(o.g[0][0], g4); gload_u16<32>(o.g[1][0], g4);
+    gload_u16<2 * H>(o.g[0][1], g4); gload_u16<2 * H + 32>(o.g[1][1], g4);
+    gload_u16<4 * H>(o.g[0][2], g4); gload_u16<4 * H + 32>(o.g[1][2], g4);
+    gload_u16<6 * H>(o.g[0][3], g4); gload_u16<6 * H + 32>(o.g[1][3], g4);
+    gload_u16<0>(o.hp[0], hp); gload_u16<32>(o.hp[1], hp);
   };
   __syncthreads();
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
@@ -671,7 +669,7 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
     wait_lgkmcnt<0>();
     ws_barrier();
   };
-  Ops oa, ob;
+  Ops oa = {}, ob = {};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the counted waits start from an empty queue
   load_ops(T - 1, oa);
   for (int t = T - 1, k = 0; t >= 0; t -= 2, k += 2) {        // two steps per iteration: the operand sets swap roles, nothing is copied
