@@ -62,6 +62,17 @@ def lstm_step_flops(B, T):
     return per_t_fwd * T / n_launch, per_t_bwd * T / n_launch, n_launch
 
 
+def lstm_step_bytes(B):
+    """Algorithmic HBM bytes of ONE full wavefront diagonal (4 cells) of the decoder LSTM, bf16 storage:
+    forward: 7 weight panels [4H, H] + x (3) / h (4) operands [B, H] + previous cell state fp32 (4) read; h, c (fp32 + bf16), gates written;
+    backward: 7 transposed weight panels + 7 dG operands [B, 4H] + saved gates, c, c_prev, carried dc (fp32) read; dG and dc written."""
+    H = H_DEC
+    w = 7 * 4 * H * H * 2
+    fwd = w + 7 * B * H * 2 + 4 * B * H * 4 + 4 * (B * H * 2 + B * H * 4 + B * H * 2 + B * 4 * H * 2)
+    bwd = w + 7 * B * 4 * H * 2 + 4 * (B * 4 * H * 2 + 2 * B * H * 2 + B * H * 4) + 4 * (B * 4 * H * 2 + B * H * 4)
+    return fwd, bwd
+
+
 def host_cores(cap=32):
     """Usable host cores: the affinity mask clipped by the cgroup CPU quota (an over-subscribed OpenMP team spins)."""
     n = len(os.sched_getaffinity(0))
@@ -110,6 +121,8 @@ def parse_args():
     ap.add_argument("--cpu-steps", type=int, default=16)
     ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: reduce-scatter + sharded clip/Adam + all-gather instead of all-reduce")
     ap.add_argument("--grad-compress", default=None, choices=[None, "bf16"], help="N > 1: all-reduce the gradient as bfloat16")
+    ap.add_argument("--force-comm", action="store_true", help="N = 1: initialise a one-rank RCCL process group and issue every collective of the "
+                                                              "N-rank step anyway (GradSync(force=True)); prints `comm` for the one GPU at hand")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the multi-rank "
                                                        "path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -135,10 +148,11 @@ def spawn_ranks(args):
 class MolVaeWorkload:
     name = "MolecularVAE(i=120,o=292,c=35) ELBO train step: fwd+loss+bwd+clip(3.0)+Adam(8e-4), synthetic one-hot SMILES [B,120,35]"
 
-    def __init__(self, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB):
+    def __init__(self, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB, device_eps=True):
         import torch
         import molecular_vae_amd as mv
         self.mv, self.B, self.L, self.C = mv, B, L, C
+        self.device_eps = device_eps
         if (L, C) != (L_SEQ, VOCAB):
             self.name = self.name.replace("i=120,o=292,c=35", f"i={L},o=292,c={C}").replace("[B,120,35]", f"[B,{L},{C}]")
         torch.manual_seed(42)                                     # train.py:73
@@ -149,7 +163,11 @@ class MolVaeWorkload:
         g = torch.Generator().manual_seed(1234 + rank)
         self.data = torch.randint(0, C, (B, L), generator=g).to(dev)
         self.ohe = torch.nn.functional.one_hot(self.data, C).float()    # the (idx, ohe) pair MoleLoader yields, resident in HBM
-        self.model.encoder.lmbd.draw_eps = lambda b, o, d: 1e-2 * torch.randn(b, o, device=d)   # device noise: no H2D copy in the step
+        # Reparameterisation noise.  The PRODUCT default (Lambda.draw_eps) reproduces models.py:92: scale * randn on the CPU default generator,
+        # into pinned memory, asynchronous H2D copy.  The headline workload draws it on the device instead (no host work in the step); the
+        # default form is timed as well (secondary.headline_B1024_default_eps) and config.eps_source says which one a line used.
+        if device_eps:
+            self.model.encoder.lmbd.draw_eps = lambda b, o, d: 1e-2 * torch.randn(b, o, device=d)
 
     def step(self):
         return self.mv.train_step(self.model, self.optimizer, self.loss_function, self.data, self.ohe)
@@ -197,28 +215,42 @@ class MolVaeWorkload:
         bwd_us = 1e3 * tag_ms.get("dec_lstm_bwd", float("nan")) / n_launch
         peak = BF16_DENSE_PEAK_TFLOPS if dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
         fused_bwd = dtype == "bf16" and self.B >= 1024 and self.B % 128 == 0
-        leg = {"fwd": dict(kernel=("lstm_step_fwd_gm_kernel" if dtype == "bf16" and (self.B >= 1024 or self.B <= 128) else "lstm_step_fwd_kernel"),
+        from molecular_vae_amd import ops as _ops
+        persist = dtype == "bf16" and self.B == 128 and (self.L, H_DEC) == (self.L, 1024) and _ops.PERSIST_STATS["launches"] > 0
+        leg = {"fwd": dict(kernel=("lstm_persist_fwd_kernel (weights-resident dataflow pass: ONE launch, time per diagonal)" if persist else
+                                   "lstm_step_fwd_gm_kernel" if dtype == "bf16" and (self.B >= 1024 or self.B <= 128) else "lstm_step_fwd_kernel"),
                            us=fwd_us, flops=fwd_f, pmc_key="lstm_step_fwd"),
                "bwd": dict(kernel=("lstm_step_bwd_kernel (fused gate-derivative epilogue)" if fused_bwd or dtype != "bf16" else
                                    "lstm_step_bwd_kernel + lstm_bwd_epi_kernel (launch pair)"), us=bwd_us, flops=bwd_f, pmc_key="lstm_step_bwd")}
+        by_f, by_b = lstm_step_bytes(self.B)
+        leg["fwd"]["bytes"], leg["bwd"]["bytes"] = by_f * self.L / n_launch, by_b * self.L / n_launch
         for v in leg.values():
             v["tflops"] = v["flops"] / (v["us"] * 1e-6) / 1e12
+            # BOTH floors of the launch: MFMA time of its algorithmic FLOPs, HBM time of its algorithmic bytes (bf16: intensity 250 FLOP/B at
+            # B = 1024, below the 312 FLOP/B ridge -- the HBM floor is the higher one)
+            v["floor_us"] = dict(mfma=round(v["flops"] / (peak * 1e12) * 1e6, 2), hbm=round(v["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6, 2))
         dom = "bwd" if not (bwd_us < fwd_us) else "fwd"
         oth = "fwd" if dom == "bwd" else "bwd"
         d, o = leg[dom], leg[oth]
         traffic, src = pmc_traffic(d["pmc_key"], self.B, dtype)
+        hbm_bound = dtype == "bf16" and d["floor_us"]["hbm"] > d["floor_us"]["mfma"]
         return dict(bound="mfma", kernel=d["kernel"], achieved=round(d["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(d["tflops"] / peak, 4),
+                    floors_us=d["floor_us"], higher_floor=("hbm" if hbm_bound else "mfma"),
+                    frac_of_higher_floor=round(max(d["floor_us"].values()) / d["us"], 4), algorithmic_bytes_per_launch=int(d["bytes"]),
+                    achieved_GBps_algorithmic=round(d["bytes"] / (d["us"] * 1e-6) / 1e9, 1),
                     traffic=traffic, traffic_source=src, launches_per_pass=n_launch,
                     share_of_step_ms=round(d["us"] * n_launch * 1e-3, 3),
                     avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
                     flops_per_launch=dict(lstm_step_fwd=fwd_f, lstm_step_bwd=bwd_f),
-                    other=dict(kernel=o["kernel"], achieved=round(o["tflops"], 2), frac=round(o["tflops"] / peak, 4),
+                    other=dict(kernel=o["kernel"], achieved=round(o["tflops"], 2), frac=round(o["tflops"] / peak, 4), floors_us=o["floor_us"],
                                share_of_step_ms=round(o["us"] * n_launch * 1e-3, 3)),
                     hbm_bound_kernels=self.hbm_kernels(tag_ms))
 
     def config(self, world):
         return dict(workload=self.name, per_gpu_batch=self.B, global_batch=self.B * world, seq_len=self.L, vocab=self.C, latent=LATENT,
-                    parallelism=f"dp{world}")
+                    parallelism=f"dp{world}",
+                    eps_source=("device generator (bench override of Lambda.draw_eps)" if self.device_eps else
+                                "product default: CPU default generator -> pinned memory -> async H2D (models.py:92 semantics)"))
 
 
 def pmc_traffic(kernel_key, B, dtype):
@@ -239,9 +271,9 @@ def pmc_traffic(kernel_key, B, dtype):
     return None, None
 
 
-def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB):
+def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB, device_eps=True):
     if model == "molvae":
-        return MolVaeWorkload(B, dtype, dev, rank, sync, L, C)
+        return MolVaeWorkload(B, dtype, dev, rank, sync, L, C, device_eps=device_eps)
     if model == "moses":
         from bench_extra import MosesWorkload
         return MosesWorkload(B, dtype, dev, rank, sync)
@@ -249,12 +281,12 @@ def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB):
     return Models2dWorkload(B, dtype, dev, rank, sync)
 
 
-def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_SEQ, C=VOCAB, pipeline=False):
+def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_SEQ, C=VOCAB, pipeline=False, device_eps=True):
     """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
     import torch
     import torch.distributed as dist
     from molecular_vae_amd import ops
-    wl = make_workload(model, B, dtype, dev, rank, sync, L, C)
+    wl = make_workload(model, B, dtype, dev, rank, sync, L, C, device_eps=device_eps)
     log(f"[{label}] model built, per-GPU batch {B}, dtype {dtype}, world {world}")
     for i in range(warmup):
         loss = wl.step()
@@ -280,6 +312,7 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    ops.persist_check(sync=True)              # a persistent dataflow launch that gave up would have left garbage: never report such a run
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -290,7 +323,7 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
     roof = wl.roofline(tag_ms, dtype)
     roof["phase_ms"] = {k: round(v, 3) for k, v in tag_ms.items()}
     comm = None
-    if world > 1:
+    if world > 1 or (sync is not None and sync.active):
         # time the main stream spent blocked on the gradient all-reduce in FusedAdam.step (HIP events around start_rest + wait): what the
         # overlap with backward did NOT hide.  MAX over ranks, like the step time.
         t = torch.tensor([tag_ms.get("dp_allreduce_exposed", 0.0)], device=dev, dtype=torch.float64)
@@ -345,6 +378,36 @@ def measure_generation(dev, b_size=2000, reps=5):
                 device_ms_per_batch=round(dev_ms, 3), what="MolDecoder from uniform latents, arg-max, charset strings (train_sample.py:29-45)")
 
 
+def measure_moses_sample(dev, B=1024, max_len=100, reps=3):
+    """mosesvae.VAE.sample (mosesvae.py:214-262; hugesample.py "Samples per second"): B latents from the prior -> autoregressive decoding at
+    temperature 1 on the GRU step kernels + one sampling launch per token -> strings.  Random-init weights; samples/s incl. the host-side
+    string assembly, and the device part alone (HIP events around the token loop's launches)."""
+    import torch
+    from molecular_vae_amd import mosesvae as MV, vocab as VC, ops
+    v = VC.OneHotVocab([chr(ord("a") + i) for i in range(26)])
+    torch.manual_seed(42)
+    model = MV.VAE(v).to(dev).eval()
+    model.sample(B, max_len=max_len, seed=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        model.sample(B, max_len=max_len, seed=2 + r)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for r in range(reps):
+        model.sample(B, max_len=max_len, seed=9 + r, return_tokens=True)
+    e.record(); torch.cuda.synchronize()
+    dev_ms = s.elapsed_time(e) / reps
+    del model
+    ops.release_caches(); torch.cuda.empty_cache()
+    return dict(value=round(B / dt, 1), unit="samples/s", batch=B, max_len=max_len, ms_per_batch=round(1e3 * dt, 2),
+                us_per_token_step=round(1e3 * dev_ms / (max_len - 1), 2), launches_per_token=4,
+                what="mosesvae.VAE.sample: 3-layer GRU wavefront pass (T = 1) + ONE sampling launch (head GEMV, temperature softmax, multinomial from a "
+                     "counter hash, eos bookkeeping, next input rows) per token; strings assembled on the host")
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -366,16 +429,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sync = None
-    if world > 1:
+    force = bool(args.force_comm) and world == 1
+    if world > 1 or force:
         import torch.distributed as dist
+        kw = {}
+        if force:
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+            kw = dict(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, **kw)  # nccl == RCCL on ROCm
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, **kw)
         if dist.get_world_size() != args.gpus:
             die(f"{dist.get_world_size()} ranks joined, --gpus {args.gpus}")
         import molecular_vae_amd as mv
-        sync = mv.GradSync(compress=args.grad_compress)
+        sync = mv.GradSync(compress=args.grad_compress, force=force)
         sync.shard_optimizer = args.shard_optimizer
     if args.batch > 0:
         B, scaling = args.batch, "weak"
@@ -385,7 +453,7 @@ def main():
         B, scaling = args.global_batch // world, "strong"
 
     main_res = measure(args.model, B, args.dtype, args.steps, args.warmup, dev, rank, world, sync, "main", args.seq_len, args.vocab,
-                       pipeline=(world == 1 and args.model == "molvae" and not args.no_secondary))
+                       pipeline=(world == 1 and not force and args.model == "molvae" and not args.no_secondary))
     metric = {"molvae": "molecules/s (ELBO fwd+bwd+step)", "moses": "molecules/s (mosesvae.VAE KL+CE fwd+bwd+step)",
               "models2d": "molecules/s (models2d.VAE ELBO fwd+bwd+step)"}[args.model]
     cfg = main_res["config"]; cfg["final_loss"] = main_res["final_loss"]
@@ -397,11 +465,14 @@ def main():
     if main_res.get("input_pipeline") is not None:
         out["input_pipeline"] = main_res["input_pipeline"]
 
-    if (world == 1 and args.model == "molvae" and not args.no_secondary and args.batch == 0 and args.dtype == "bf16"
+    if (world == 1 and not force and args.model == "molvae" and not args.no_secondary and args.batch == 0 and args.dtype == "bf16"
             and (args.seq_len, args.vocab) == (L_SEQ, VOCAB)):
         # every BASELINE.json config gets a number on this line: configs[1] (B=512), the per-rank shape of configs[2] (b=128), the exact-f32
         # parity mode, configs[3] (mosesvae.VAE, B=1024) and configs[4] (L=256, C=64, B=2048 with the GB/s of its HBM-bound kernels)
         sec = {}
+        r = measure("molvae", B, "bf16", 10, 3, dev, rank, 1, None, "headline_B1024_default_eps", device_eps=False)
+        sec["headline_B1024_default_eps"] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=10, warmup=3, dtype="bf16",
+                                                 per_gpu_batch=B, eps_source=r["config"]["eps_source"])
         for label, mdl, b, dt_, st, wu, Lq, Cq in (("configs1_B512_bf16", "molvae", 512, "bf16", 10, 3, L_SEQ, VOCAB),
                                                    ("configs2_per_rank_b128_bf16", "molvae", 128, "bf16", 20, 5, L_SEQ, VOCAB),
                                                    ("parity_mode_B1024_f32", "molvae", args.global_batch, "f32", 10, 2, L_SEQ, VOCAB),
@@ -411,9 +482,10 @@ def main():
             sec[label] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=st, warmup=wu, dtype=dt_,
                               per_gpu_batch=b, final_loss=r["final_loss"], roofline=r["roofline"], workload=r["config"]["workload"])
         sec["generation_from_latent_b2000"] = measure_generation(dev)
+        sec["moses_sample_b1024"] = measure_moses_sample(dev)
         out["secondary"] = sec
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not force and not args.no_cpu_baseline:
         from oracle import torch_ref
         cores = host_cores()
         log(f"cpu baseline on {cores} threads ...")
@@ -424,7 +496,7 @@ def main():
                                           f"(BASELINE.json configs[0]), torch.nn CPU modules, {r['s_per_step']:.2f} s/step")
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 6
+#define MVAE_ABI_VERSION 7
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -55,6 +55,10 @@ int mvae_abi_version(void);
  * anything else: 0) -- a binding checks its own mirror of the structs against it at load time. */
 size_t mvae_struct_size(int which);
 const char* mvae_status_string(int status);
+/* Schedule knobs (MVAE_BM, MVAE_BWD_SPLIT, ... : tile / split choices, every setting computes the same results) are read from the environment
+ * ONLY while MVAE_TUNING=1 is set too; otherwise stray MVAE_* variables are ignored.  Returns the integer value of knob `name` as the library
+ * would read it now, or `dflt`. */
+int mvae_knob_int(const char* name, int dflt);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Dense contraction  C[M,N] = act( A[M,K] . B[N,K]^T + bias[N] )          (MFMA, fp32 accumulate)
@@ -197,6 +201,14 @@ typedef struct {
   void* hdrop[MVAE_MAX_LAYERS];
   const uint8_t* drop_mask[MVAE_MAX_LAYERS];
   float drop_p; uint32_t drop_seed;
+  /* Optional second schedule, the WEIGHTS-RESIDENT DATAFLOW pass (rnn_persist.hip): ONE persistent launch of 256 workgroups in which every
+   * workgroup keeps its 256 KB slice of [W_ih | W_hh] in registers for all T steps and the h_t tiles travel between workgroups through
+   * write-through stores + flag words (no launch per diagonal).  Serves the per-rank shape of the 8-GPU configuration only (LSTM, bf16,
+   * 4 layers, H = 1024, B = 128, zero initial state, time-invariant layer-0 input, ldh = H + 64, a 256-CU device with nothing else running
+   * beside it): mvae_rnn_fwd_persist_workspace() returns 0 for everything else.  persist_ws != NULL (that many bytes of device memory,
+   * 16-byte aligned) selects it; the first 16 bytes are a status record the launch leaves behind -- word 0 != 0: a bounded spin ran out
+   * (a workgroup was not resident, or a producer died), the outputs are invalid; the launch itself always ends. */
+  void* persist_ws; size_t persist_ws_bytes;
 } mvae_rnn_fwd_desc;
 
 /* keep decision of the device-generated dropout mask (host-callable restatement: the oracle and the tests use the same hash):
@@ -204,6 +216,7 @@ typedef struct {
 int mvae_dropout_keep(uint32_t seed, uint32_t idx, float p);
 
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
+size_t mvae_rnn_fwd_persist_workspace(const mvae_rnn_fwd_desc* d);   /* 0: this shape / device is not served by the persistent schedule */
 
 /* Backward through time of the same stack (reverse wavefront).  One launch computes, per cell,
  *   dh_t = dG^{l}_{t+1} . W_hh + dG^{l+1}_t . W_ih^{l+1} (+ dy_t for the top layer)
@@ -364,6 +377,14 @@ int mvae_ce_loss_fwd(int B, int T, int V, const float* logits, int64_t ldl, cons
 int mvae_ce_loss_bwd(int dtype, int B, int T, int V, const float* logits, int64_t ldl, const int64_t* x, int pad, const float* loss2,
                      const float* grad_out, const float* dy_ext, void* dl, int64_t ldd, void* stream);
 int mvae_permute102(int T, int B, int V, const float* in, float* out, void* stream);
+/* One autoregressive sampling step behind the GRU step kernels (mosesvae.py:236-253): y = decoder_fc(h_top) (w_fc [V, ldw] dtype, V <= 64),
+ * p = softmax(y / temp), w ~ multinomial(p, 1) with EXPLICIT randomness -- u(b) = hash(seed, step * B + b) / 2^32 with the counter hash of
+ * mvae_dropout_keep; the sample is the first class k with cumsum_k(p) > u * sum(p) --, then the reference's bookkeeping
+ * (x[b, step] = w unless the sequence has ended; a first <eos> sets end_pads[b] = step + 1 and eos_mask[b]) and the NEXT step's layer-0
+ * addend row add_out[b] = table[w_b] + base[b] (fp32 [*, W], the embedding folded into the input projection).  w_out [B]: the sampled ids. */
+int mvae_moses_sample_step(int dtype, int B, int V, int H, const void* h_top, int64_t ldh, const void* w_fc, int64_t ldw, const float* bias, float temp,
+                           uint32_t seed, int step, int eos_id, const float* table, int W, const float* base, float* add_out, int64_t* x, int64_t x_ld,
+                           int64_t* end_pads, uint8_t* eos_mask, int64_t* w_out, void* stream);
 int mvae_relu_bwd(int64_t n, float* dy, const float* y, void* stream);
 int mvae_mask_rows_tb(int dtype, int T, int B, int64_t ld, const int32_t* lengths, void* buf, void* stream);
 

@@ -11,9 +11,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVAE_LIB: absolute path of a diagnostic build (csrc/build.sh tune -> tests/tuning/lib/libmvae_hip_tune.so: outside the package, never next to the product library) for timing decompositions; bench.py refuses to
 # run with any MVAE_* variable set, so a measured number always comes from the product library.
-LIB_PATH = os.environ.get("MVAE_LIB") or os.path.join(_HERE, "libmvae_hip.so")
+LIB_PATH = ((os.environ.get("MVAE_LIB") if os.environ.get("MVAE_TUNING", "0") not in ("", "0") else None)
+            or os.path.join(_HERE, "libmvae_hip.so"))      # MVAE_LIB too is honoured only under MVAE_TUNING=1
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MVAE_F32, MVAE_BF16, MVAE_F32X3 = 0, 1, 2
 CONV_BWD_X3 = 0x100
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
@@ -37,7 +38,8 @@ class RnnFwdDesc(C.Structure):
                 ("gates", _vp * MAX_LAYERS),
                 ("cstate", _vp * MAX_LAYERS),
                 ("zero_padded_k", _i),
-                ("hdrop", _vp * MAX_LAYERS), ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32)]
+                ("hdrop", _vp * MAX_LAYERS), ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32),
+                ("persist_ws", _vp), ("persist_ws_bytes", _sz)]
 
 
 class RnnBwdDesc(C.Structure):
@@ -75,6 +77,7 @@ SIGNATURES = {
     "mvae_abi_version": (_i, []),
     "mvae_struct_size": (_sz, [_i]),
     "mvae_status_string": (C.c_char_p, [_i]),
+    "mvae_knob_int": (_i, [C.c_char_p, _i]),
     "mvae_gemm_nt_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_gemm_nt": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "mvae_gemm_tn_workspace": (_sz, [_i, _i, _i, _i]),
@@ -88,6 +91,7 @@ SIGNATURES = {
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_onehot_tb": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
+    "mvae_rnn_fwd_persist_workspace": (_sz, [C.POINTER(RnnFwdDesc)]),
     "mvae_dropout_keep": (_i, [C.c_uint32, C.c_uint32, _f]),
     "mvae_gemm_tn_f32_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
     "mvae_gemm_tn_colsum_supported": (_i, [_i, _i, _i]),
@@ -127,6 +131,7 @@ SIGNATURES = {
     "mvae_ce_loss_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),
     "mvae_ce_loss_bwd": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mvae_permute102": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "mvae_moses_sample_step": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _f, C.c_uint32, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mvae_relu_bwd": (_i, [_i64, _vp, _vp, _vp]),
     "mvae_mask_rows_tb": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp]),
     "mvae_sumsq_workspace": (_sz, [_i64]),
@@ -162,6 +167,24 @@ def load():
             raise MvaeError(f"{st.__name__}: ctypes mirror is {C.sizeof(st)} bytes, the library's struct {lib.mvae_struct_size(which)}")
     _lib = lib
     return lib
+
+
+_KNOB_SAID = [False]
+
+
+def knob(name, default):
+    """Host-side schedule knob (string): the environment variable `name` is honoured ONLY while MVAE_TUNING=1 is set as well (tests, A/B
+    scripts) -- a training run ignores stray MVAE_* variables, as the library does (mvae_knob_int).  The first one honoured is reported once."""
+    if os.environ.get("MVAE_TUNING", "0") in ("", "0"):
+        return default
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    if not _KNOB_SAID[0]:
+        _KNOB_SAID[0] = True
+        import sys
+        print(f"mvae: MVAE_TUNING=1 -- schedule knob {name}={v} honoured (further knobs not reported)", file=sys.stderr)
+    return v
 
 
 def check(rc, what=""):

@@ -19,6 +19,11 @@ size_t mvae_struct_size(int which) {
   }
 }
 
+int mvae_knob_int(const char* name, int dflt) {
+  const char* v = name ? mvae_knob(name) : nullptr;
+  return v ? atoi(v) : dflt;
+}
+
 const char* mvae_status_string(int status) {
   switch (status) {
     case MVAE_OK: return "ok";
@@ -71,7 +76,11 @@ int mvae_dropout_keep(uint32_t seed, uint32_t idx, float p) {
   return h >= (uint32_t)((double)p * 4294967296.0) ? 1 : 0;
 }
 
-int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) { return rnn_fwd_impl(d, (hipStream_t)stream); }
+int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) {
+  if (d && d->persist_ws) return rnn_persist_fwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream);   // refuses shapes it does not serve
+  return rnn_fwd_impl(d, (hipStream_t)stream);
+}
+size_t mvae_rnn_fwd_persist_workspace(const mvae_rnn_fwd_desc* d) { return (d && rnn_persist_fwd_supported(d)) ? rnn_persist_fwd_workspace_bytes(d->T) : 0; }
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d) { return rnn_bwd_workspace_bytes(d); }
 

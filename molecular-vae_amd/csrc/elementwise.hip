@@ -794,23 +794,91 @@ __global__ __launch_bounds__(256) void bce_kl_bwd_kernel(long n, const float* re
   }
 }
 
+// ------------------------------------------------------------------------------------------- autoregressive sampling step (mosesvae.py:236-253)
+// ONE launch per generated token for everything behind the GRU step:  y = decoder_fc(h_top);  p = softmax(y / temp);  w ~ multinomial(p, 1);
+// x[~eos, i] = w[~eos];  end_pads[new eos] = i + 1;  eos |= (w == eos)  -- and the NEXT step's layer-0 addend row  add[b] = table[w_b] + base[b]
+// (the embedding folded into the input projection, mosesvae.py:239-240).  One wave per batch row; the V x H head sits in LDS once per workgroup.
+// Explicit randomness, no hidden state: u(b, i) = hash(seed, i * B + b) / 2^32 (the same counter hash as mvae_dropout_keep); the sampled
+// index is the first k with  cumsum_k(p) > u * sum(p)  in the fixed order k = 0 .. V - 1.
+template <typename T>
+__global__ __launch_bounds__(256) void moses_sample_step_kernel(int B, int V, int H, const T* __restrict__ h, long ldh, const T* __restrict__ wfc, long ldw,
+                                                                const float* __restrict__ bias, float inv_temp, uint32_t seed, int step, int eos_id,
+                                                                const float* __restrict__ table, int W, const float* __restrict__ base,
+                                                                float* __restrict__ add_out, int64_t* __restrict__ x, long x_ld,
+                                                                int64_t* __restrict__ end_pads, uint8_t* __restrict__ eos_mask, int64_t* __restrict__ w_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* ws = reinterpret_cast<T*>(smem_raw);                    // [V][H]
+  for (int i = threadIdx.x; i < V * H; i += 256) ws[i] = wfc[(long)(i / H) * ldw + (i % H)];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    // logits: lane k-strided partial dot products, wave reduction per class (V <= 64 classes: class v ends up in lane v)
+    float mine = -INFINITY;
+    for (int v = 0; v < V; ++v) {
+      float a = 0.f;
+      for (int k = lane; k < H; k += 64) a += TT<T>::ld(h + (long)b * ldh + k) * TT<T>::ld(ws + (long)v * H + k);
+      a = wave_sum(a);
+      if (lane == v) mine = (a + (bias ? bias[v] : 0.f)) * inv_temp;
+    }
+    const float mx = wave_max(mine);
+    const float e = (lane < V) ? __expf(mine - mx) : 0.f;
+    // inclusive prefix sum over the classes (fixed order)
+    float c = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float up = __shfl_up(c, o, 64); if (lane >= o) c += up; }
+    const float tot = __shfl(c, 63, 64);
+    const uint32_t hsh = drop_hash_u32(seed, (uint32_t)((long)step * B + b));
+    const float u = (float)hsh * (1.0f / 4294967296.0f) * tot;
+    const unsigned long long above = __ballot(lane < V && c > u);
+    int w = above ? (int)__builtin_ctzll(above) : V - 1;     // (u rounds up to tot for hsh near 2^32: take the last class)
+    if (lane == 0) {
+      const bool done = eos_mask[b] != 0;
+      if (!done) {
+        x[(long)b * x_ld + step] = w;
+        if (w == eos_id) { end_pads[b] = step + 1; eos_mask[b] = 1; }
+      }
+      w_out[b] = w;
+    }
+    // next step's layer-0 addend (the finished rows keep being fed their sampled token, as the reference does)
+    const float* trow = table + (long)w * W;
+    const float* brow = base + (long)b * W;
+    float* orow = add_out + (long)b * W;
+    for (int cidx = lane * 4; cidx < W; cidx += 256) {
+      const float4 tv = *reinterpret_cast<const float4*>(trow + cidx), bv = *reinterpret_cast<const float4*>(brow + cidx);
+      *reinterpret_cast<float4*>(orow + cidx) = make_float4(tv.x + bv.x, tv.y + bv.y, tv.z + bv.z, tv.w + bv.w);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- grad-norm + Adam
 constexpr int SUMSQ_CHUNK = 1 << 16;   // elements per partial
 __global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g, float* partial) {
   __shared__ float red[4];
   const long beg = (long)blockIdx.x * SUMSQ_CHUNK;
   long end = beg + SUMSQ_CHUNK; if (end > n) end = n;
-  // 16-byte loads, four independent accumulators per thread, fixed combination order (deterministic)
+  // 16-byte loads, four independent accumulators per thread, fixed combination order (deterministic).  A SHORT last chunk adds its
+  // elements in exactly the order (and into exactly the accumulators) the same chunk zero-padded to 64K elements would: the sharded
+  // optimiser pads its flat buffer to whole chunks, the unsharded one does not, and both must form the same norm bit for bit.
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const long n4 = (end - beg) / 4;
+  const long cnt = end - beg, n4 = cnt / 4, rem = cnt - 4 * n4;
   const float4* g4 = reinterpret_cast<const float4*>(g + beg);          // beg is a multiple of 65536 elements: 16-byte aligned
-  long i = threadIdx.x;
-  for (; i + 768 < n4; i += 1024) {
+  if (cnt == SUMSQ_CHUNK) {
+    for (long i = threadIdx.x; i < SUMSQ_CHUNK / 4; i += 1024) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const float4 v = g4[i + 256 * k]; acc[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+      for (int k = 0; k < 4; ++k) { const float4 v = g4[i + 256 * k]; acc[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+    }
+  } else {
+    for (long i = threadIdx.x; i <= n4; i += 1024) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long idx = i + 256 * k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < n4) v = g4[idx];
+        else if (idx == n4 && rem) { const float* t = g + beg + 4 * n4; v.x = t[0]; if (rem > 1) v.y = t[1]; if (rem > 2) v.z = t[2]; }
+        acc[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
   }
-  for (; i < n4; i += 256) { const float4 v = g4[i]; acc[0] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
-  for (long j = beg + 4 * n4 + threadIdx.x; j < end; j += 256) { const float v = g[j]; acc[1] += v * v; }
   float a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   a = block_sum_256(a, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = a;
@@ -1202,7 +1270,7 @@ int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const flo
   return MVAE_OK;
 }
 
-static bool softmax_tiled_ok() { const char* e = getenv("MVAE_SOFTMAX_TILED"); return !e || atoi(e) != 0; }
+static bool softmax_tiled_ok() { const char* e = mvae_knob("MVAE_SOFTMAX_TILED"); return !e || atoi(e) != 0; }
 int mvae_softmax_tb_fwd(int B, int L, int C, const float* logits, int64_t ldl, float* recon, void* stream) {
   if (!logits || !recon || B < 1 || L < 1 || C < 1) return MVAE_ERR_INVALID;
   const long rows = (long)B * L;
@@ -1311,6 +1379,26 @@ int mvae_bce_kl_loss_bwd(int64_t n, const float* recon, const float* target, int
   if (!recon || !target || !mu || !logvar || !drecon || n < 1 || m < 1) return MVAE_ERR_INVALID;
   hipLaunchKernelGGL(bce_kl_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, recon, target, (long)m, mu, logvar, max_len,
                      grad_out, drecon, dmu, dlogvar);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+
+int mvae_moses_sample_step(int dtype, int B, int V, int H, const void* h_top, int64_t ldh, const void* w_fc, int64_t ldw, const float* bias, float temp,
+                           uint32_t seed, int step, int eos_id, const float* table, int W, const float* base, float* add_out, int64_t* x, int64_t x_ld,
+                           int64_t* end_pads, uint8_t* eos_mask, int64_t* w_out, void* stream) {
+  if (!h_top || !w_fc || !table || !base || !add_out || !x || !end_pads || !eos_mask || !w_out) return MVAE_ERR_INVALID;
+  if (B < 1 || V < 1 || V > 64 || H < 1 || (W & 3) || W < 4 || !(temp > 0.f) || step < 0) return MVAE_ERR_INVALID;
+  const size_t lds = (size_t)V * H * (dtype == MVAE_BF16 ? 2 : 4);
+  if (lds > 64 * 1024) return MVAE_ERR_UNSUPPORTED;
+  int blocks = (B + 3) / 4; if (blocks > 1024) blocks = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MVAE_BF16)
+    hipLaunchKernelGGL((moses_sample_step_kernel<bf16_t>), dim3(blocks), dim3(256), lds, st, B, V, H, (const bf16_t*)h_top, (long)ldh, (const bf16_t*)w_fc, (long)ldw,
+                       bias, 1.f / temp, seed, step, eos_id, table, W, base, add_out, x, (long)x_ld, end_pads, eos_mask, w_out);
+  else if (dtype == MVAE_F32)
+    hipLaunchKernelGGL((moses_sample_step_kernel<float>), dim3(blocks), dim3(256), lds, st, B, V, H, (const float*)h_top, (long)ldh, (const float*)w_fc, (long)ldw,
+                       bias, 1.f / temp, seed, step, eos_id, table, W, base, add_out, x, (long)x_ld, end_pads, eos_mask, w_out);
+  else return MVAE_ERR_INVALID;
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

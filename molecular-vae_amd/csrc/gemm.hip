@@ -419,7 +419,7 @@ namespace {
 Plan make_plan_tn(int M, int N, int K) {
   Plan pl;
   // 256 x 128 tiles (half the operand bytes per output of 128 x 128) whenever they still give >= 128 tiles: split-K then fills the chip
-  const char* fe = getenv("MVAE_TN_BM");
+  const char* fe = mvae_knob("MVAE_TN_BM");
   const int force_bm = fe ? atoi(fe) : 0;
   pl.bm = ((long)((M + 255) / 256) * ((N + 127) / 128) >= 128) ? 256 : 128;
   // 256 x 256 (pl.bm = 512 as its tag): another third less operand traffic per FLOP; needs whole tiles' worth of work and enough K to split
@@ -517,7 +517,7 @@ int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, con
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const char* we = getenv("MVAE_TN_WS");
+  const char* we = mvae_knob("MVAE_TN_WS");
   const bool wspec = we ? atoi(we) != 0 : true;      // loader / consumer wave specialisation (512-thread workgroups)
   if (pl.bm == 512) {
     if (colsum_out) hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<true>, grid, dim3(512), 2 * 65536, st, p);
@@ -526,7 +526,7 @@ int launch_gemm_tn_bf16_colsum(int M, int N, int K, const void* A, long lda, con
   else if (wspec) {
     if (pl.bm == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 8, true>), grid, dim3(512), 3 * (32768 + 16384), st, p);
     else {
-      const char* ne = getenv("MVAE_NBUF_TN");
+      const char* ne = mvae_knob("MVAE_NBUF_TN");
       const int nb = ne ? atoi(ne) : 4;
       if (nb == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<3, 4, true>), grid, dim3(512), 3 * 32768, st, p);
       else if (nb == 5) {

@@ -27,3 +27,8 @@ int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, lon
 size_t colsum_workspace_bytes(int M, int N);
 int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_selu_bwd(long n, float* dy, const float* y, hipStream_t st);
+
+// rnn_persist.hip: weights-resident dataflow LSTM forward (b = 128, 4 x 1024, bf16)
+bool rnn_persist_fwd_supported(const mvae_rnn_fwd_desc* d);
+size_t rnn_persist_fwd_workspace_bytes(int T);
+int rnn_persist_fwd(const mvae_rnn_fwd_desc* d, void* ws, size_t ws_bytes, hipStream_t st);

@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_epi_kernel(StepArgsB p) {
 // MVAE_NBUF_FWD / MVAE_NBUF_BWD = LDS ring depth, MVAE_BM / MVAE_BJ = tile, MVAE_BWD_SPLIT, MVAE_ROWRES.  MVAE_DBG (skip parts of a
 // kernel, results WRONG) exists only in the diagnostic build (-DMVAE_TUNING); the product library ignores it.
 static int tune_int(const char* name, int dflt) {
-  const char* v = getenv(name);
+  const char* v = mvae_knob(name);
   return v ? atoi(v) : dflt;
 }
 

@@ -691,7 +691,7 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   const int T = d->T, B = d->B;
   // hoisting the upper layers' input projection pays while its GEMM is small (measured, encoder forward per step: b = 128: 0.478 -> 0.427 ms;
   // B = 1024: 0.575 -> 0.790 ms, the two [T*B, 72] x [72, 288] GEMMs then cost more than the halved contraction saves)
-  const char* hv = getenv("MVAE_ROWRES_HOIST");
+  const char* hv = mvae_knob("MVAE_ROWRES_HOIST");
   const bool hoist = hv ? atoi(hv) != 0 : (long)T * B <= 16384;
   for (int l = 0; l < d->layers; ++l) {
     RowResF a;

@@ -35,17 +35,17 @@ class _NoCompute(nn.Module):
                            "of the enclosing MolEncoder / MolDecoder")
 
 
-class LinearWeights(_NoCompute):
-    """weight [out,in], bias [out]; initialised like nn.Linear (same RNG consumption as the reference's modules)."""
+def _holder_forward(*a, **k):
+    raise RuntimeError("this nn.Linear only holds parameters; the arithmetic runs in the fused HIP path of the enclosing module")
 
-    def __init__(self, in_features, out_features):
-        super().__init__()
-        self.in_features, self.out_features = in_features, out_features
-        self.weight = nn.Parameter(torch.empty(out_features, in_features))
-        self.bias = nn.Parameter(torch.empty(out_features))
-        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        bound = 1.0 / math.sqrt(in_features)
-        nn.init.uniform_(self.bias, -bound, bound)
+
+def LinearWeights(in_features, out_features):
+    """weight [out,in], bias [out] in a REAL ``torch.nn.Linear`` (same initialisation and RNG consumption as the reference's modules), so
+    that hooks keyed on the exact type -- ``model.apply(init_weights)`` with ``type(m) == nn.Linear``, moses_train_distrib_logp.py:48-51,262 --
+    find these layers.  Its ``forward`` is blocked: no torch compute on this path."""
+    m = nn.Linear(in_features, out_features)
+    m.forward = _holder_forward
+    return m
 
 
 class Conv1dWeights(_NoCompute):
@@ -173,17 +173,30 @@ class _SavedState:
             ring.append(_Workspace())
         del ring[n:]
         self.__dict__["_turn"] = 0
+        self.__dict__["_half_turns"] = {}
 
-    def _next_saved_ws(self):
-        """(slot, workspace) for the forward that is starting; bumps that slot's generation."""
+    def _next_saved_ws(self, half=""):
+        """(slot, workspace) -- with `half`: (slot, workspace, generation) -- for the forward that is starting; bumps that slot's generation.
+        `half`: a module whose forward can
+        run in independently callable halves (mosesvae.VAE: encoder / decoder) keeps one turn and one generation count per half -- the halves
+        use disjoint buffer names of the same workspaces, so `forward_encoder` followed by `forward_decoder` overwrites nothing."""
         ring = self.__dict__["_ring"]
-        self.__dict__["_turn"] = slot = (self.__dict__["_turn"] + 1) % len(ring)
-        ring[slot].generation += 1
-        return slot, ring[slot]
+        if not half:
+            self.__dict__["_turn"] = slot = (self.__dict__["_turn"] + 1) % len(ring)
+            ring[slot].generation += 1
+            return slot, ring[slot]
+        turns = self.__dict__.setdefault("_half_turns", {})
+        turns[half] = slot = (turns.get(half, 0) + 1) % len(ring)
+        gens = ring[slot].__dict__.setdefault("half_generation", {})
+        gens[half] = gens.get(half, 0) + 1
+        return slot, ring[slot], gens[half]
 
-    def _saved_ws(self, slot, gen, what):
+    def _saved_ws(self, slot, gen, what, half=""):
         ring = self.__dict__["_ring"]
-        if slot >= len(ring) or ring[slot].generation != gen:
+        now = None
+        if slot < len(ring):
+            now = ring[slot].__dict__.get("half_generation", {}).get(half) if half else ring[slot].generation
+        if now != gen:
             raise L.MvaeError(f"{what}: the state this forward saved was overwritten by a later forward of the same module (or it ran under "
                               f"no_grad); run backward before the next forward, or set `module.saved_state_depth` to the number of forward "
                               f"passes kept outstanding (now {len(ring)})")
@@ -196,6 +209,14 @@ def _dyk(n_out):
     """K extent of the output-gradient product dy = dl . W_out (see MolDecoder): the class / vocabulary count rounded up to whole pairs of
     64-deep K-steps (so that the 4-way split backward can halve it)."""
     return _pad(n_out, 128)
+
+
+def _apply_and_mark(self, fn):
+    """nn.Module.apply, then invalidate the packed weight shadows: initialisation hooks often write through ``p.data`` (``m.bias.data.fill_``,
+    moses_train_distrib_logp.py:51), which torch's version counters do not see."""
+    out = nn.Module.apply(self, fn)
+    L.PARAM_EPOCH[0] += 1
+    return out
 
 
 def _require_cuda(dev, what):
@@ -224,7 +245,7 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
     G4, TB = 4 * H, Lq * B
     f32 = torch.float32
     layers = range(NL) if layers is None else layers
-    if dt == torch.bfloat16 and Lq > 1 and ops.gemm_tn_grouped_supported(dG[0], G4, H, TB - B, ldg, ldh) and H == 1024 and os.environ.get("MVAE_DW_GROUPED", "1") != "0":
+    if dt == torch.bfloat16 and Lq > 1 and ops.gemm_tn_grouped_supported(dG[0], G4, H, TB - B, ldg, ldh) and H == 1024 and L.knob("MVAE_DW_GROUPED", "1") != "0":
         # ONE grouped launch for every dW_ih / dW_hh of the requested layers (64 tiles of 256 x 256 each, accumulated over the full K = T*B in
         # registers: no split-K slabs, no reduction launch); the bias gradient (column sums of dG) rides along one GEMM per layer.
         probs = []
@@ -320,6 +341,8 @@ class MolEncoder(nn.Module, _SavedState):
         self._pack_key = None
         self._packed = {}
 
+    apply = _apply_and_mark
+
     def forward(self, x, eps=None):
         B = x.shape[0]
         o = self.lmbd.z_mean.out_features
@@ -336,9 +359,10 @@ class MolEncoder(nn.Module, _SavedState):
         key = _params_key(params)
         if key == self._pack_key:
             return self._packed
-        ptrs = (dev,) + tuple(p.data_ptr() for p in params)
+        ptrs = (dev,) + tuple((id(p), p.data_ptr()) for p in params)     # id: a deepcopy must rebuild its own job table
         if self.__dict__.get("_pack_ptrs") != ptrs:
-            self._build_pack(dev)
+            with torch.no_grad():                      # the job table keeps plain (non-autograd) views of the parameters
+                self._build_pack(dev)
             self.__dict__["_pack_ptrs"] = ptrs
         with torch.no_grad():
             self.__dict__["_pack_list"].run()
@@ -518,7 +542,7 @@ class _EncoderFn(torch.autograd.Function):
         dy2, dy1, dx1 = W("dy2", (B * W2, O2)), W("dy1", (B * W1, O1)), W("dx1", (B * H, L1))
         dzp3, dzp2, dzp1 = W("dzp3", (B * (W3 + 2 * k - 2), C3)), W("dzp2", (B * (W2 + 2 * k - 2), O2)), W("dzp1", (B * (W1 + 2 * k - 2), O1))
         # bf16 training mode: input-gradient GEMMs as 3 x bf16 products (forward conv stays exact fp32); MVAE_CONV_X3=0: A/B knob
-        x3 = bool(mod.fast_grad_gemms) and os.environ.get("MVAE_CONV_X3", "1") != "0"
+        x3 = bool(mod.fast_grad_gemms) and L.knob("MVAE_CONV_X3", "1") != "0"
         ops.conv1d_selu_bwd(B, W2, c3.in_channels, O2, W2 * O2, C3, C3, k, dy3, y3, y2, P["c3_wq"], dzp3,
                             grads["conv_3.0.weight"], grads["conv_3.0.bias"], dy2, O2, x3=x3)
         ops.conv1d_selu_bwd(B, W1, c2.in_channels, O1, W1 * O1, c2.out_channels, O2, k, dy2, y2, y1, P["c2_wq"], dzp2,
@@ -568,6 +592,8 @@ class MolDecoder(nn.Module, _SavedState):
         self.__dict__["_side"] = None
         self.overlap_weight_grads = True       # run the weight-gradient GEMMs on a side stream under the encoder's backward
 
+    apply = _apply_and_mark
+
     def _side_stream(self, dev):
         return ops.side_stream(dev)       # process-wide, probed not to share a hardware queue with the main stream (stream priorities: no effect)
 
@@ -581,9 +607,10 @@ class MolDecoder(nn.Module, _SavedState):
         key = _params_key(params) + (self.compute_dtype,)
         if key == self._pack_key:
             return self._packed
-        ptrs = (dev, self.compute_dtype) + tuple(p.data_ptr() for p in params)
+        ptrs = (dev, self.compute_dtype) + tuple((id(p), p.data_ptr()) for p in params)     # id: a deepcopy must rebuild its own job table
         if self.__dict__.get("_pack_ptrs") != ptrs:
-            self._build_pack(dev)
+            with torch.no_grad():                      # the job table keeps plain (non-autograd) views of the parameters
+                self._build_pack(dev)
             self.__dict__["_pack_ptrs"] = ptrs
         with torch.no_grad():
             self.__dict__["_pack_list"].run()          # every shadow in ONE launch (ops.PackList)
@@ -726,9 +753,9 @@ class _DecoderFn(torch.autograd.Function):
         # 3's range is on the links while layers 2, 1, 0 are still being contracted and the encoder's backward runs -- four early ranges
         # instead of two (at the per-rank batch of a DP job the 128-tile launches cost little: K = T * b is short).
         gsync = getattr(sink[0], "grad_sync", None) if sink is not None else None
-        dp_early = gsync is not None and gsync.world > 1 and gsync.allow_early
-        nlow = min(int(os.environ.get("MVAE_DEFER_LAYERS", "2")), NL - 1)
-        per_layer = os.environ.get("MVAE_WGRAD_PER_LAYER", "1" if dp_early else "0") == "1"
+        dp_early = gsync is not None and gsync.active and gsync.allow_early
+        nlow = min(int(L.knob("MVAE_DEFER_LAYERS", "2")), NL - 1)
+        per_layer = L.knob("MVAE_WGRAD_PER_LAYER", "1" if dp_early else "0") == "1"
         if per_layer:
             parts = [[l] for l in range(NL - 1, -1, -1)]
         else:
@@ -777,7 +804,7 @@ class _DecoderFn(torch.autograd.Function):
             # per-GPU batches (K = T * B short: a group of GEMMs is a few hundred microseconds) EVERYTHING waits for that second point: released
             # earlier, the chip-filling 256 x 256 tiles only starve the peer's conv / dense backward (a 5 us bias column sum sat 308 us behind
             # them at b = 128), while next to the 32-workgroup row-resident kernel (0.7 ms) they are hidden completely.
-            late_all = TB <= int(os.environ.get("MVAE_WGRAD_LATE_TB", 16384))      # measured: b = 128 8.38 -> 8.22 ms / step; B = 256: +0.13
+            late_all = TB <= int(L.knob("MVAE_WGRAD_LATE_TB", 16384))      # measured: b = 128 8.38 -> 8.22 ms / step; B = 256: +0.13
             for k in range(len(parts)):
                 fstate.park(side, (lambda kk=k: weight_grads(kk)), 1 if (late_all or 2 * k >= len(parts)) else 0)
         else:
@@ -816,9 +843,11 @@ class MolecularVAE(nn.Module):
         # the forward pass of the encoder (what mu / logvar / the ELBO are made of) is exact fp32 in both modes
         self.encoder.fast_grad_gemms = dtype == torch.bfloat16
 
+    apply = _apply_and_mark
+
     def forward(self, x, eps=None):
         ev = None
-        if x.is_cuda and self.prepack_decoder and os.environ.get("MVAE_PREPACK", "1") != "0":
+        if x.is_cuda and self.prepack_decoder and L.knob("MVAE_PREPACK", "1") != "0":
             # the decoder's weight shadows (8 bf16 cast / transposes of 4096 x 1024) are independent of the encoder's forward: refresh them
             # on the side stream beside it (after everything issued so far: the optimiser update they read)
             side = self.decoder._side_stream(x.device)

@@ -40,8 +40,10 @@ class _Timed:
 # One side stream per device for the whole process, picked so that it does NOT share a hardware queue with the main stream: HIP maps streams
 # onto a few hardware queues (4 by default, the null stream holds one), further streams double up round-robin, and two streams on one queue
 # execute strictly one after the other -- a fork onto such a stream is no fork at all (measured: the 4th stream a process creates turned the
-# b = 128 step from 8.2 into 14.4 ms).  Nothing in the API tells which queue a stream got, so the pick is a 1 ms probe at first use.
+# b = 128 step from 8.2 into 14.4 ms).  Nothing in the API tells which queue a stream got, so the pick is a 1 ms probe at first use -- the
+# models probe at their first FORWARD (MolecularVAE's prepack fork, mosesvae.VAE.forward), not inside a backward pass.
 _SIDE_STREAMS = {}
+SIDE_STREAM_INFO = {}     # device index -> dict(tries, concurrent, ratio): which candidate was taken and whether it passed the probe (logs / bench line)
 
 
 def side_stream(device):
@@ -53,26 +55,35 @@ def side_stream(device):
 
 
 def _pick_concurrent_stream(device, tries=6):
+    """Probe: ~0.4 ms of fills on the main stream, a tiny fill on the candidate issued behind them; the candidate runs concurrently iff its fill
+    finishes long before the main stream's.  16 MB of scratch, freed on return.  When no candidate passes (a co-tenant or a profiler can skew
+    the wall-clock test) the first one is used and SIDE_STREAM_INFO says so -- the results are the same, only the overlap is lost."""
     main = torch.cuda.current_stream(device)
-    big = torch.empty(1 << 26, dtype=torch.float32, device=device)       # 256 MB: a fill takes ~45 us
+    big = torch.empty(1 << 22, dtype=torch.float32, device=device)       # 16 MB: a fill takes ~5 us
     small = torch.empty(256, dtype=torch.float32, device=device)
-    first = None
+    first, info = None, dict(tries=0, concurrent=False, ratio=None)
+    pick = None
     for _ in range(tries):
         cand = torch.cuda.Stream(device=device)
         first = first or cand
+        info["tries"] += 1
         torch.cuda.synchronize(device)
         e0, e_main, e_c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record(main)
-        for _ in range(8):
+        for _ in range(96):
             big.fill_(1.0)                                                # ~0.4 ms of work on the main stream
         e_main.record(main)
         with torch.cuda.stream(cand):
             small.fill_(0.0)                                              # independent of it: finishes at once -- unless it queues behind
             e_c.record(cand)
         torch.cuda.synchronize(device)
-        if e0.elapsed_time(e_c) < 0.5 * e0.elapsed_time(e_main):
-            return cand
-    return first
+        info["ratio"] = e0.elapsed_time(e_c) / max(e0.elapsed_time(e_main), 1e-6)
+        if info["ratio"] < 0.5:
+            pick, info["concurrent"] = cand, True
+            break
+    del big, small
+    SIDE_STREAM_INFO[device.index] = info
+    return pick or first
 
 
 class ForkState:
@@ -346,6 +357,25 @@ def permute102(inp, out, T, B, V):
     check(L.load().mvae_permute102(T, B, V, ptr(inp), ptr(out), stream_ptr()), "mvae_permute102")
 
 
+def moses_sample_step(h_top, ldh, w_fc, bias, temp, seed, step, eos_id, table, base, add_out, x, end_pads, eos_mask, w_out, B, V, H):
+    """One generated token behind the GRU step: head GEMV, temperature softmax, multinomial draw (counter hash of (seed, step, row)), the
+    reference's eos / end-pad bookkeeping and the next step's layer-0 addend rows -- one launch (mvae_moses_sample_step)."""
+    check(L.load().mvae_moses_sample_step(dt_code(h_top.dtype), B, V, H, ptr(h_top), ldh, ptr(w_fc), w_fc.stride(0), ptr(bias), float(temp),
+                                          int(seed) & 0xFFFFFFFF, int(step), int(eos_id), ptr(table), table.shape[1], ptr(base), ptr(add_out),
+                                          ptr(x), x.stride(0), ptr(end_pads), ptr(eos_mask), ptr(w_out), stream_ptr()), "mvae_moses_sample_step")
+
+
+def sample_uniform(seed, step, B):
+    """Host restatement of the sampling step's uniforms u(b) = hash(seed, step * B + b) / 2^32 (tests)."""
+    import numpy as np
+    idx = (np.uint64(step) * np.uint64(B) + np.arange(B, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)
+    h = ((idx * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) ^ np.uint64(seed & 0xFFFFFFFF)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h.astype(np.float64) / 4294967296.0
+
+
 def moses_latent_fwd(mu, logvar, eps, z, kl, B, dz):
     lib = L.load()
     need = lib.mvae_moses_latent_workspace(B)
@@ -473,10 +503,38 @@ def dropout_keep_mask(seed, shape_lt_b_h, p):
     return (h >= thresh).astype(np.uint8).reshape(shape_lt_b_h)
 
 
+# The weights-resident dataflow schedule of mvae_rnn_fwd (rnn_persist.hip; the per-rank shape of the 8-GPU configuration: LSTM 4 x 1024, b = 128,
+# bf16).  PERSIST_DEFAULT: used whenever the library serves the shape ("1") or never ("0"); `rnn_fwd(persist=...)` / MVAE_PERSIST (under
+# MVAE_TUNING=1) override it.  The launch cannot hang -- its spins are bounded -- but it can FAIL (a workgroup not resident because something
+# else held a CU): it then leaves a status record, which is copied to pinned host memory behind the launch and checked at the next call
+# and by persist_check().
+PERSIST_DEFAULT = "1"
+PERSIST_STATS = {"launches": 0}     # how many passes took the persistent schedule (tests / logs)
+_PERSIST_PENDING = []      # [(pinned int32[4], event, what)]
+
+
+def persist_check(sync=False):
+    """Raise MvaeError if a persistent launch whose status has arrived (sync: wait for all of them) reported a failed hand-off."""
+    keep = []
+    for host, ev, what in _PERSIST_PENDING:
+        if sync:
+            ev.synchronize()
+        if not ev.query():
+            keep.append((host, ev, what))
+            continue
+        if int(host[0]) != 0:
+            _PERSIST_PENDING.clear()
+            raise L.MvaeError(f"{what}: the persistent dataflow launch gave up waiting for a hand-off (status {host.tolist()}: code, block, layer) "
+                              "-- its outputs are invalid.  Not all 256 workgroups were resident (another kernel held compute units); "
+                              "run the step without concurrent work or disable the schedule (ops.PERSIST_DEFAULT = '0')")
+    _PERSIST_PENDING[:] = keep
+
+
 def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, cs, gates, cstate,
             x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, zero_padded_k=False, tag=None,
-            hdrop=None, drop_mask=None, drop_p=0.0, drop_seed=0, add_table=None, add_index=None):
-    """add_table [rows, G*H] fp32 + add_index [B, L >= T] int64: layer 0 adds table row add_index[b, t] in its epilogue (no gathered copy)."""
+            hdrop=None, drop_mask=None, drop_p=0.0, drop_seed=0, add_table=None, add_index=None, persist=None):
+    """add_table [rows, G*H] fp32 + add_index [B, L >= T] int64: layer 0 adds table row add_index[b, t] in its epilogue (no gathered copy).
+    persist: True / False / None (= PERSIST_DEFAULT): the weights-resident dataflow schedule where the library serves the shape."""
     d = L.RnnFwdDesc()
     NL = len(w_hh)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H, d.in0 = cell, dt_code(dtype), NL, T, B, H, in0
@@ -510,8 +568,24 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
         if drop_mask is not None:
             _fill(d.drop_mask, drop_mask)
         d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
+    use_p = (L.knob("MVAE_PERSIST", PERSIST_DEFAULT) != "0") if persist is None else bool(persist)
+    pws = None
+    if use_p:
+        persist_check()
+        need = L.load().mvae_rnn_fwd_persist_workspace(C.byref(d))
+        if need:
+            pws = Scratch.get(need, hs[0].device, tag="rnn_persist")
+            d.persist_ws, d.persist_ws_bytes = pws.data_ptr(), need
+        elif persist:
+            raise L.MvaeError("rnn_fwd(persist=True): this shape / device is not served by the persistent schedule")
     with _Timed(tag):
         check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
+    if pws is not None:
+        PERSIST_STATS["launches"] += 1
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(pws[:16].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        _PERSIST_PENDING.append((host, ev, tag or "mvae_rnn_fwd"))
 
 
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dstate,

@@ -29,8 +29,12 @@ class GradSync:
     per-link transfer well above the latency floor while letting bucket k+1 overlap bucket k's reduction.
     """
 
-    def __init__(self, bucket_bytes=32 << 20, group=None, early=True, compress=None):
-        """compress="bf16": every bucket is all-reduced as bfloat16 (rounded copy out, sum, converted back into the fp32 buffer): half the
+    def __init__(self, bucket_bytes=32 << 20, group=None, early=True, compress=None, force=False):
+        """force: issue every collective even when the group has ONE rank (an initialised process group is still required).  With backend
+        "nccl" this runs the whole RCCL path -- ProcessGroupNCCL's internal communication stream, the event hand-off from the stream a
+        collective is issued on (the side stream, for early ranges) and back at wait() -- on a single GPU; sums over one rank are the identity,
+        so the step must equal the non-distributed one bit for bit (tests, `bench.py --force-comm`).
+        compress="bf16": every bucket is all-reduced as bfloat16 (rounded copy out, sum, converted back into the fp32 buffer): half the
         bytes on the links, ~3 significant digits per gradient element -- what the bf16 training mode's decoder gradients carry anyway; the
         optimiser still accumulates in fp32.  None: fp32 on the wire (bit-reproducible sums)."""
         if compress not in (None, "bf16"):
@@ -39,6 +43,7 @@ class GradSync:
         self.group = group
         self.allow_early = early  # False: every range is reduced in step() (needed when parameter hooks clone gradients)
         self.compress = compress
+        self.force = bool(force)
         self.handles = []
         self.early = []          # [(flat, lo, hi)] ranges whose all-reduce was started from inside backward (this step)
         self._staged = []        # compress: (fp32 view, bf16 copy) pairs to convert back in wait()
@@ -48,8 +53,13 @@ class GradSync:
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    @property
+    def active(self):
+        """True when gradients are exchanged: more than one rank, or `force` under an initialised process group."""
+        return self.world > 1 or (self.force and dist.is_available() and dist.is_initialized())
+
     def start(self, flat):
-        if self.world == 1:
+        if not self.active:
             return
         n = flat.numel()
         for off in range(0, n, self.bucket_elems):
@@ -65,7 +75,7 @@ class GradSync:
         """Called from a module's backward once flat[lo:hi] is final on the CURRENT stream (the collective is ordered after
         that stream's work): the all-reduce then runs under the rest of backward.  Every rank issues the same calls in the
         same order (same model, same code path)."""
-        if self.world == 1 or not self.allow_early:
+        if not self.active or not self.allow_early:
             return
         self.start(flat[lo:hi])
         self.early.append((flat, lo, hi))
@@ -86,6 +96,8 @@ class GradSync:
         for h in self.handles:
             h.wait()
         for piece, half in self._staged:
+            if half.is_cuda:
+                half.record_stream(torch.cuda.current_stream())    # allocated on the stream start() ran on (early ranges: the side stream)
             piece.copy_(half)
         self.handles, self.early, self._staged = [], [], []
 
@@ -168,8 +180,11 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, **self._ADAM_INERT)
         super().__init__(params, defaults)
         self.grad_sync = grad_sync
-        self.shard = bool(shard_optimizer) and grad_sync is not None and grad_sync.world > 1
+        self.shard = bool(shard_optimizer) and grad_sync is not None and grad_sync.active
+        self._moments_stale = False      # sharded form: True from step() until gather_state() -- the other ranks' slices of exp_avg / exp_avg_sq are old
         if self.shard:
+            if grad_sync.compress is not None:
+                raise ValueError("GradSync(compress=...) applies to the all-reduce form only: the reduce-scatter of shard_optimizer=True sends fp32")
             grad_sync.allow_early = False
         world = grad_sync.world if self.shard else 1
         self._flat = []
@@ -238,11 +253,12 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        ops.persist_check()            # a persistent dataflow launch of this step's forward that gave up leaves a status record: raise, never train on garbage
         ops.join_pending()             # gradients produced on a side stream (decoder weight-gradient GEMMs)
         flats = self.gather_grads()
         sync = self.grad_sync
         if sync is not None and not self.shard:
-            with ops._Timed("dp_allreduce_exposed" if sync.world > 1 else None):   # bench.py: what the overlap with backward did not hide
+            with ops._Timed("dp_allreduce_exposed" if sync.active else None):   # bench.py: what the overlap with backward did not hide
                 for g in flats:
                     sync.start_rest(g)
                 sync.wait()
@@ -270,6 +286,7 @@ class FusedAdam(torch.optim.Optimizer):
                                   group["eps"], f["step"], f["norm"])
                 with ops._Timed("dp_allreduce_exposed"):
                     sync.all_gather(f["p"], S)
+                self._moments_stale = True
             else:
                 with ops._Timed("hbm_sumsq_clip_adam"):
                     ops.sumsq(f["g"], f["partial"])
@@ -288,6 +305,16 @@ class FusedAdam(torch.optim.Optimizer):
             if f is not None:
                 self.grad_sync.all_gather(f["m"], f["shard_elems"])
                 self.grad_sync.all_gather(f["v"], f["shard_elems"])
+        self._moments_stale = False
+
+    def state_dict(self):
+        """torch.optim.Adam's layout.  Sharded form: after a step() this rank holds current moments for its own 1/world slice only, so the
+        dictionary would be silently wrong for the rest -- refuse until EVERY rank has called ``gather_state()`` (a collective: call it on all
+        ranks, then save on rank 0)."""
+        if self.shard and self._moments_stale:
+            raise L.MvaeError("FusedAdam(shard_optimizer=True).state_dict(): the Adam moments of the other ranks' slices are stale; call "
+                              "optimizer.gather_state() on every rank first (a collective), then save")
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         """Accepts a FusedAdam or a ``torch.optim.Adam`` state dict (train.py:173 ``optimizer_state_dict``): same ``state`` layout
@@ -430,7 +457,8 @@ def strip_module_prefix(state_dict):
 
 
 def save_checkpoint(path, model, optimizer, epoch, charset, max_len, latent_size=None):
-    """The dictionary of train.py:170-177 (``latent_size`` is absent in train_distributed.py:145-151)."""
+    """The dictionary of train.py:170-177 (``latent_size`` is absent in train_distributed.py:145-151).  With FusedAdam(shard_optimizer=True)
+    every rank must have called ``optimizer.gather_state()`` since the last step (``state_dict()`` raises otherwise)."""
     lr = optimizer.param_groups[-1]["lr"]
     d = {"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(), "epoch": epoch,
          "charset": charset, "max_len": max_len, "lr": lr}
@@ -460,6 +488,7 @@ def moses_train_step(model, optimizer, kl_weight, batch, eps=None):
     sync = getattr(optimizer, "grad_sync", None)
     if sync is not None and hasattr(model, "dp_group"):
         model.dp_group = sync.group          # the CE's global token count is reduced over the ranks the gradients are reduced over
+        model.dp_force = sync.force
     kl_loss, recon_loss, _, _, _, _ = model(batch) if eps is None else model(batch, eps=eps)
     loss = kl_weight * kl_loss + recon_loss
     loss.backward()

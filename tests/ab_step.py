@@ -4,6 +4,7 @@
 Each --set is a comma-separated list of KEY=VALUE pairs (the kernels read these knobs on every call); prints ms/step per setting and round."""
 import argparse
 import os
+os.environ.setdefault("MVAE_TUNING", "1")   # schedule knobs are honoured only under this switch
 import sys
 import time
 

@@ -2,6 +2,7 @@
 """Stand-alone timing of the head's HBM-bound kernels (softmax fwd / bwd, BCE+KL fwd / bwd) against the 8 TB/s roof:
    python tests/bench_hbm.py [B L C] ...     (default: the headline shape and BASELINE configs[4])"""
 import os
+os.environ.setdefault("MVAE_TUNING", "1")   # schedule knobs are honoured only under this switch
 import sys
 
 import torch

@@ -2,6 +2,7 @@
 """Kernel micro-benchmarks at the decoder's shapes (B=512, H=1024, 4 layers, T steps): wavefront fwd / bwd steps and the
 weight-gradient GEMM.  Used for tuning and for the PMC profiles under profiles/.   python tests/bench_kernels.py [T] [B]"""
 import os
+os.environ.setdefault("MVAE_TUNING", "1")   # schedule knobs are honoured only under this switch
 import sys
 
 import torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 # Main-loop / epilogue decomposition of the decoder wavefront step kernels with the DIAGNOSTIC library (csrc/build.sh tune;
 # MVAE_DBG=1: main loop only, =2: epilogue only -- results wrong, timings only).  Run on the GPU box from the repo root:
 #   bash tests/decompose.sh "512 1024 128" -> gpurun_out/decomp.txt

@@ -23,6 +23,8 @@ ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32: re
 ap.add_argument("--model", default="molvae", choices=["molvae", "moses"])
 ap.add_argument("--shard", action="store_true", help="world > 1: reduce-scatter + sharded clip / Adam + all-gather (FusedAdam(shard_optimizer=True))")
 ap.add_argument("--compress", default=None, choices=[None, "bf16"], help="world > 1: gradient all-reduce as bfloat16")
+ap.add_argument("--backend", default="gloo", help="gloo (ranks sharing the GPU) or nccl (= RCCL; one rank per GPU)")
+ap.add_argument("--force-comm", action="store_true", help="ONE rank: initialise a one-rank process group on --backend and issue every collective anyway (GradSync(force=True))")
 args = ap.parse_args()
 if args.compare:
     a, b = (json.load(open(f)) for f in args.compare)
@@ -39,9 +41,16 @@ import molecular_vae_amd as mv
 rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-if world > 1:
+force = args.force_comm and world == 1
+if world > 1 or force:
     import torch.distributed as dist
-    dist.init_process_group("gloo")
+    if force:
+        import socket
+        so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+        kw = dict(device_id=dev) if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+    else:
+        dist.init_process_group(args.backend)
 if args.model == "moses":
     # mosesvae.VAE step (moses_train_distrib.py:287-299): variable-length batch, the CE mean runs over the GLOBAL non-pad token count
     import numpy as np
@@ -50,7 +59,7 @@ if args.model == "moses":
     torch.manual_seed(42)
     model = MV.VAE(v, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
     model.d_dropout = 0.0                     # the dropout hash is indexed by batch position, which differs between the two layouts
-    sync = mv.GradSync() if world > 1 else None
+    sync = mv.GradSync(force=force) if (world > 1 or force) else None
     opt = mv.FusedAdam(model.parameters(), lr=3e-4, max_grad_norm=50.0, grad_sync=sync)
     rs = np.random.RandomState(9)
     gb = 2 * args.b
@@ -68,15 +77,17 @@ if args.model == "moses":
         out["loss"].append(float(lt)); out["gnorm"].append(float(opt.last_grad_norm))
         out["psum"].append(float(sum(p.detach().abs().sum() for p in model.parameters())))
     out["early_ranges"] = 0
+    out["buckets"] = sync.stats["buckets"] if sync is not None else 0
+    out["pcheck"] = [float(p.detach().double().sum()) for p in model.parameters()]
     if rank == 0 and args.out:
         json.dump(out, open(args.out, "w")); print(out)
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
     sys.exit(0)
 L_SEQ, VOCAB, LATENT = 120, 35, 292
 torch.manual_seed(42)
 model = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
-sync = mv.GradSync(compress=args.compress) if world > 1 else None
+sync = mv.GradSync(compress=args.compress, force=force) if (world > 1 or force) else None
 opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0, grad_sync=sync, shard_optimizer=args.shard)
 loss_fn = mv.make_loss_function(L_SEQ)
 g = torch.Generator().manual_seed(7)
@@ -102,14 +113,28 @@ for s in range(args.steps):
     out["gnorm"].append(float(opt.last_grad_norm))
     out["psum"].append(float(sum(p.detach().abs().sum() for p in model.parameters())))
 out["early_ranges"] = sync.stats["early_ranges"] if sync is not None else 0
+out["buckets"] = sync.stats["buckets"] if sync is not None else 0
 out["pcheck"] = [float(p.detach().double().sum()) for p in list(model.parameters())[:6]] + [float(opt.state[next(iter(model.decoder.gru.parameters()))]["exp_avg"].double().abs().sum())]
-if args.shard and world > 1:
+if args.shard and (world > 1 or force):
+    # a state_dict() taken now would hold stale moments for the other ranks' slices -- it must refuse until gather_state() ran
+    try:
+        opt.state_dict(); out["stale_state_dict_refused"] = False
+    except mv._lib.MvaeError:
+        out["stale_state_dict_refused"] = True
     opt.gather_state()
     out["mcheck"] = float(sum(opt.state[p]["exp_avg"].double().abs().sum() for p in model.parameters()))
+    # ... and afterwards the dictionary loads into an UNSHARDED optimiser with every moment in place
+    sd = opt.state_dict()
+    m2 = mv.MolecularVAE(i=L_SEQ, o=LATENT, c=VOCAB, dtype=model.decoder.compute_dtype).to(dev)
+    o2 = mv.FusedAdam(m2.parameters(), lr=8e-4, max_grad_norm=3.0)
+    o2.load_state_dict(sd)
+    out["mcheck_reloaded"] = float(sum(o2.state[p]["exp_avg"].double().abs().sum() for p in m2.parameters()))
+    out["vcheck"] = float(sum(opt.state[p]["exp_avg_sq"].double().sum() for p in model.parameters()))
+    out["vcheck_reloaded"] = float(sum(o2.state[p]["exp_avg_sq"].double().sum() for p in m2.parameters()))
 elif world >= 1:
     out["mcheck"] = float(sum(opt.state[p]["exp_avg"].double().abs().sum() for p in model.parameters()))
 if rank == 0 and args.out:
     json.dump(out, open(args.out, "w"))
     print(out)
-if world > 1:
+if world > 1 or force:
     dist.destroy_process_group()

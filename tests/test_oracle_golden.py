@@ -79,7 +79,18 @@ def test_g3_moses_gru_path(golden_dir):
     assert (r["x_pad"] == g["x"]).all()
     grads = r["grads_for"](float(g["kl_w"]))
     names = list(g["grad_names"])
-    assert sorted(grads.keys()) == sorted(names)
+    assert sorted(k for k in grads if not k.startswith("_")) == sorted(names)
+    # the per-half entries (forward_decoder / forward_encoder alone): the two embedding shares add up to the fixture-pinned total, and
+    # d recon / d z agrees with central differences of the oracle's own forward run on an overridden latent
+    assert rel(grads["_x_emb_dec"] + grads["_x_emb_enc"], grads["x_emb.weight"]) < 1e-12
+    z0 = r["z"].copy()
+    for (b, j) in ((0, 0), (3, 17), (5, 159)):
+        h = 1e-5
+        zp, zm = z0.copy(), z0.copy()
+        zp[b, j] += h; zm[b, j] -= h
+        fp = O.moses_forward(p, seqs, g["eps"], int(g["pad"]), want_grads=False, z_override=zp)["recon"]
+        fm = O.moses_forward(p, seqs, g["eps"], int(g["pad"]), want_grads=False, z_override=zm)["recon"]
+        assert abs((fp - fm) / (2 * h) - grads["_dz"][b, j]) < 1e-6 * max(1.0, abs(grads["_dz"][b, j])), (b, j)
     for k in names:
         gr = grads[k]
         n = float(np.sqrt((gr ** 2).sum()))

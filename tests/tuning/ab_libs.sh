@@ -1,4 +1,5 @@
 #!/bin/bash
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 # Same-box A/B of two builds of the library (device-to-device spread is +-2 %, larger than most single changes): alternates
 #   MVAE_LIB=<a> / <b> over whole-step timings.   bash tests/tuning/ab_libs.sh libA.so libB.so "1024 128" [rounds]
 set -uo pipefail

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 ROOT=$(pwd)
 echo "== LSTM B=1024 bwd candidates (product lib)"
 for sp in 2562 1281 2; do r=$(MVAE_BWD_SPLIT=$sp python3 tests/bench_kernels.py 24 1024 bwd 2>&1 | grep "bwd :"); echo "BWD_SPLIT=$sp $r"; done

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 ROOT=$(pwd)
 export MVAE_LIB=$ROOT/tests/tuning/lib/libmvae_hip_tune.so
 for rep in 1 2; do

@@ -1,3 +1,4 @@
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 export BK_CELL=gru BK_H=512 BK_NL=3
 echo "== default"; python tests/bench_kernels.py 32 1024 fwd,bwd 2>&1 | grep -v amdgpu
 for bm in 64 128; do for bj in 32 64; do for nb in 2 3 4; do

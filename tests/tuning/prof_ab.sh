@@ -1,4 +1,5 @@
 #!/bin/bash
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 # Per-kernel average durations of two library builds on ONE box: rocprofv3 --kernel-trace --stats over the kernel micro-benchmark
 # (bench.py refuses MVAE_* variables, so the library is switched under tests/bench_kernels.py):
 #   bash tests/tuning/prof_ab.sh libA.so libB.so [T] [B] [modes]

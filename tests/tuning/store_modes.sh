@@ -1,4 +1,5 @@
 #!/bin/bash
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 # Forward gate-major epilogue with the DIAGNOSTIC library: is its exposed time store ISSUE or HBM write bandwidth?
 #   MVAE_DBG=2: epilogue only;  6: + every store into the tile's first 16 rows (same instructions, 1/16 of the write footprint);
 #   10: + saved gates not stored (half the bytes);  0 / 4 / 8: the same three with the main loop in front.

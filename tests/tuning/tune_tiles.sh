@@ -1,4 +1,5 @@
 #!/bin/bash
+export MVAE_TUNING=1   # schedule knobs / MVAE_LIB are honoured only under this switch
 # product library; schedule knobs only
 for B in 128 256 512 1024; do
   for gm in 0 256256 256128 128128 128064; do
