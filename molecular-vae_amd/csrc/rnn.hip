@@ -841,7 +841,16 @@ __global__ __launch_bounds__(WS ? 512 : 256) void lstm_step_bwd_kernel(StepArgsB
   const int seg = (nsp == 4) ? (sp >> 1) : sp;   // which K-segment this workgroup contracts (split mode)
   const int half = (nsp == 4) ? (sp & 1) : 0;    // which half of it (4-way split)
   const int rem = bid - task2 * per_task;
-  const int tn = rem / p.tiles_m, tm = rem - tn * p.tiles_m;
+  int tn = rem / p.tiles_m, tm = rem - tn * p.tiles_m;
+  if (p.tiles_m >= 16 && (p.tiles_m & 7) == 0 && (p.tiles_n & 3) == 0) {
+    // More row tiles than one round of an XCD's 32 CUs holds beside 4 column blocks (B = 2048: 16 x 8 tiles per cell, 64 per XCD): walk the
+    // cell in blocks of 4 column blocks x 8 row tiles, row block fastest, so that the tiles resident on an XCD at one time share 4 weight
+    // panels and 8 dG row panels (24 MB of operands per round instead of the 2 x 16 order's 36 MB) and the NEXT round re-uses the same weight
+    // panels.  PMC, B = 2048 (profiles/r04_pmc_kernels_T16_B2048.json): 663 MB read per launch against 310 MB algorithmic in the old order.
+    const int blk = rem >> 5, in = rem & 31, mb = p.tiles_m >> 3;
+    const int tnb = blk / mb, tmb = blk - tnb * mb;
+    tn = 4 * tnb + (in >> 3); tm = 8 * tmb + (in & 7);
+  }
   const StepTaskB& q = p.t[task];
   const int m0 = tm * BM, n0 = tn * BN, H = p.H, B = p.B;
   if (p.split && (seg == 0 ? q.A0 == nullptr : q.A1 == nullptr)) return;   // this cell has no such segment: the epilogue kernel skips it too

@@ -58,17 +58,33 @@ struct RowResF {
   float* cs;                         // [T][B][H]
   float* gates;                      // [T][B][4H] post-activation i, f, g, o
   int T, B;
+  const float* tbl; int tbl_rows;    // TBL form (layer 0): pre-activation addend = tbl[idx[b][t]] ([rows][4H] fp32: the embedding folded into
+  const int64_t* idx; long idx_ld;   //   W_ih0, bias included), ids [B][idx_ld] -- the table and this workgroup's ids live in LDS
 };
 
-template <int H, bool HASX, int NTHR>
+constexpr int RR_TBL_ROWS = 64, RR_TBL_T = 256;      // LDS table / id capacity of the TBL form
+
+template <int H, bool HASX, int NTHR, bool TBL = false>
 __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
   constexpr int G4 = 4 * H, K = (HASX ? 2 * H : H), KW = K / 4, NG = (G4 + 63) / 64, NA = (KW + 15) / 16;
   constexpr int KPAD = 2 * H + 8, NPAD = NG * 64;
   static_assert(K % 4 == 0 && (KPAD % 32) == 24, "K-slices per wave; A-buffer rows on disjoint banks");
   __shared__ float abuf[2][RR_ROWS][KPAD];            // [x_t | h_{t-1}] of the 4 rows, double-buffered
   __shared__ float red[4][RR_ROWS][NPAD];             // per-wave partial pre-activations
+  // TBL: the [rows, 4H] token table (35 x 288 fp32 = 40 KB) and the ids of this workgroup's rows, copied once: the gathered [T, B, 4H]
+  // sequence (141 MB at B = 1024) is never written or read (models.py:127 nn.Embedding + the layer-0 input projection)
+  __shared__ float tblS[TBL ? RR_TBL_ROWS * G4 : 1];
+  __shared__ int idS[TBL ? RR_ROWS * RR_TBL_T : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * RR_ROWS, B = p.B, T = p.T;
+  if (TBL) {
+    for (int i = tid; i < p.tbl_rows * G4; i += NTHR) tblS[i] = p.tbl[i];
+    for (int i = tid; i < RR_ROWS * T; i += NTHR) {
+      const int row = i / T, t = i - row * T;
+      long id = (r0 + row < B) ? p.idx[(long)(r0 + row) * p.idx_ld + t] : 0;
+      idS[row * RR_TBL_T + t] = (int)(id < 0 ? 0 : (id >= p.tbl_rows ? p.tbl_rows - 1 : id));
+    }
+  }
 
   // ---- weights -> registers (once): W[g][kk] = Wcat[n = 64 g + lane][k = KW * wave + kk]
   float W[NG][KW];
@@ -113,12 +129,19 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
     for (int it = 0; it < NIT; ++it) {
       const int id = tid + it * NTHR, row = id / H, u = id % H;
       if (id < NITEM && r0 + row < B) {
+        if (TBL) {
+          const float* tr = tblS + idS[row * RR_TBL_T + t] * G4 + u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) addv[it][g] = p.add[(long)t * p.add_ts + (long)(r0 + row) * G4 + g * H + u];
+          for (int g = 0; g < 4; ++g) addv[it][g] = tr[g * H];
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) addv[it][g] = p.add[(long)t * p.add_ts + (long)(r0 + row) * G4 + g * H + u];
+        }
       }
     }
   };
-  if (p.add) load_add(0);
+  if (TBL) __syncthreads();                       // table and ids are in LDS
+  if (TBL || p.add) load_add(0);
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
         g4[0] = gi; g4[H] = gf; g4[2 * H] = gg; g4[3 * H] = go;
       }
     }
-    if (p.add && t + 1 < T) load_add(t + 1);
+    if ((TBL || p.add) && t + 1 < T) load_add(t + 1);
     rr_barrier();
   }
 }
@@ -683,7 +706,10 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
 // layers of one pass, sequentially; returns MVAE_ERR_UNSUPPORTED when the shape is not the one this schedule is built for
 int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   constexpr int H = 72;
-  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || d->x0 || !d->add0 || d->add_table || d->lengths) return MVAE_ERR_UNSUPPORTED;
+  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || d->x0 || d->lengths) return MVAE_ERR_UNSUPPORTED;
+  // layer 0's pre-activation addend: a gathered sequence add0 [T, B, 4H], or the token table + ids (kept in LDS; add0 must then be absent)
+  const bool tbl = d->add_table != nullptr;
+  if (tbl ? (d->add0 || !d->add_index || d->add_table_rows < 1 || d->add_table_rows > RR_TBL_ROWS || d->T > RR_TBL_T) : !d->add0) return MVAE_ERR_UNSUPPORTED;
   if (!d->gates[0]) return MVAE_ERR_UNSUPPORTED;      // forward-only calls (no save buffers) take the wavefront schedule
   for (int l = 0; l < d->layers; ++l)
     if (d->h0[l]) return MVAE_ERR_UNSUPPORTED;
@@ -697,6 +723,7 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     RowResF a;
     a.x = l ? reinterpret_cast<const float*>(d->hs[l - 1]) : nullptr; a.ldx = d->ldh;
     a.add = l ? nullptr : d->add0; a.add_ts = d->add0_tstride;
+    a.tbl = d->add_table; a.tbl_rows = d->add_table_rows; a.idx = d->add_index; a.idx_ld = d->add_index_ld;
     a.w_ih = l ? reinterpret_cast<const float*>(d->w_ih[l]) : nullptr; a.ldw_ih = d->ldw_ih[l];
     a.w_hh = reinterpret_cast<const float*>(d->w_hh[l]); a.ldw_hh = d->ldw_hh[l];
     a.bias = d->bias[l];
@@ -716,6 +743,7 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       a.add = reinterpret_cast<const float*>(d->gates[l]); a.add_ts = (long)B * 4 * H;
       hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, false, 320>), grid, dim3(320), 0, st, a);
     } else if (l) hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, true, 320>), grid, dim3(320), 0, st, a);
+    else if (tbl) hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, false, 320, true>), grid, dim3(320), 0, st, a);
     else hipLaunchKernelGGL((lstm_rowres_fwd_kernel<H, false, 320>), grid, dim3(320), 0, st, a);
   }
   MVAE_CHECK_HIP(hipGetLastError());

@@ -239,6 +239,9 @@ def _params_key(params):
     return (L.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params)
 
 
+DW_KSPLIT = "1"      # K-chunks of the grouped decoder weight-gradient launches (see _lstm_weight_grads)
+
+
 def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=None):
     """dW_ih, dW_hh, db of every layer from the saved pre-activation gradients dG [T*B, 4H] and layer outputs hs [T*B, H].
     Both dtypes contract straight from the K-major buffers (bf16: hardware-transposed LDS reads; f32: exact-f32 TN kernel)."""
@@ -248,18 +251,32 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
     if dt == torch.bfloat16 and Lq > 1 and ops.gemm_tn_grouped_supported(dG[0], G4, H, TB - B, ldg, ldh) and H == 1024 and L.knob("MVAE_DW_GROUPED", "1") != "0":
         # ONE grouped launch for every dW_ih / dW_hh of the requested layers (64 tiles of 256 x 256 each, accumulated over the full K = T*B in
         # registers: no split-K slabs, no reduction launch); the bias gradient (column sums of dG) rides along one GEMM per layer.
-        probs = []
-        for l in layers:
-            a = dG[l].view(TB, ldg)
-            db = grads[f"{prefix}.bias_ih_l{l}"]
-            if l > 0:
-                probs.append(dict(A=a, B=hs[l - 1].view(TB, ldh), out=grads[f"{prefix}.weight_ih_l{l}"], M=G4, N=H, K=TB, lda=ldg, ldb=ldh, colsum_out=db))
-                probs.append(dict(A=a[B:], B=hs[l].view(TB, ldh), out=grads[f"{prefix}.weight_hh_l{l}"], M=G4, N=H, K=TB - B, lda=ldg, ldb=ldh))
-            else:
-                ops.colsum_t(a[:B], B, G4, db, ldx=ldg)             # the first time step's rows (the shifted GEMM skips them)
-                probs.append(dict(A=a[B:], B=hs[l].view(TB, ldh), out=grads[f"{prefix}.weight_hh_l{l}"], M=G4, N=H, K=TB - B, lda=ldg, ldb=ldh,
-                                  colsum_out=db, colsum_accumulate=True))
-        ops.gemm_tn_grouped(probs)
+        # K-chunks (MVAE_DW_KSPLIT, default 1): the same tiles as `ks` shorter launches that accumulate -- a 256 x 256 tile owns its CU for
+        # its whole K (3.1 ms at B = 1024), so shorter launches give the dispatcher points at which the other stream's kernels get CUs
+        ks = max(1, int(L.knob("MVAE_DW_KSPLIT", DW_KSPLIT)))
+        step = ((TB // ks + B - 1) // B) * B if ks > 1 else TB            # whole time steps per chunk
+        for k0 in range(0, TB, step):
+            k1 = min(TB, k0 + step)
+            first = k0 == 0
+            probs = []
+            for l in layers:
+                a = dG[l].view(TB, ldg)
+                db = grads[f"{prefix}.bias_ih_l{l}"]
+                if l > 0:
+                    probs.append(dict(A=a[k0:k1], B=hs[l - 1].view(TB, ldh)[k0:k1], out=grads[f"{prefix}.weight_ih_l{l}"], M=G4, N=H, K=k1 - k0, lda=ldg, ldb=ldh,
+                                      colsum_out=db, accumulate=not first, colsum_accumulate=not first))
+                    lo = max(k0, B)                                        # dW_hh pairs dG[t] with h[t - 1]: rows shifted by one time step
+                    if k1 > lo:
+                        probs.append(dict(A=a[lo:k1], B=hs[l].view(TB, ldh)[lo - B:k1 - B], out=grads[f"{prefix}.weight_hh_l{l}"], M=G4, N=H, K=k1 - lo, lda=ldg,
+                                          ldb=ldh, accumulate=not first))
+                else:
+                    if first:
+                        ops.colsum_t(a[:B], B, G4, db, ldx=ldg)             # the first time step's rows (the shifted GEMM skips them)
+                    lo = max(k0, B)
+                    if k1 > lo:
+                        probs.append(dict(A=a[lo:k1], B=hs[l].view(TB, ldh)[lo - B:k1 - B], out=grads[f"{prefix}.weight_hh_l{l}"], M=G4, N=H, K=k1 - lo, lda=ldg,
+                                          ldb=ldh, colsum_out=db, colsum_accumulate=True, accumulate=not first))
+            ops.gemm_tn_grouped(probs)
         for l in layers:
             grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
         return
@@ -443,16 +460,16 @@ class _EncoderFn(torch.autograd.Function):
         tbl = ws.get("tbl", (Cv, G4), f32, dev)
         Ep = P["E_p"].shape[1]
         ops.gemm_nt(P["E_p"], P["Wih0_p"], tbl, Cv, G4, Ep, bias=P["bias"][0])
-        gx0 = ws.get("gx0", (Lq, B, G4), f32, dev)
-        ops.gather_rows_tb(idx, tbl, gx0, B, Lq, Cv, G4)
+        # (the gathered [T, B, 4H] sequence -- 141 MB at B = 1024 -- is never formed: layer 0 of the row-resident kernel keeps the 40 KB table
+        # and its rows' ids in LDS; add_table / add_index of mvae_rnn_fwd_desc)
         # K2: 3-layer LSTM, f32 MFMA
         Hp = P["Hp"]
         hs = [ws.get(f"hs{l}", (Lq, B, Hp), f32, dev) for l in range(NL)]      # rows zero-padded to whole K-steps
         cs = [ws.get(f"cs{l}", (Lq, B, H), f32, dev) for l in range(NL)]
         gates = [ws.get(f"gates{l}", (Lq, B, G4), f32, dev) for l in range(NL)]
         cstate = [ws.get(f"cstate{l}", (2, B, H), f32, dev) for l in range(NL)]
-        ops.rnn_fwd(L.CELL_LSTM, f32, Lq, B, H, gx0, B * G4, P["Wih"], [Hp] * NL, P["Whh"], [Hp] * NL, [None] + P["bias"][1:],
-                    hs, Hp, cs, gates, cstate, zero_padded_k=True, tag="enc_lstm_fwd")
+        ops.rnn_fwd(L.CELL_LSTM, f32, Lq, B, H, None, 0, P["Wih"], [Hp] * NL, P["Whh"], [Hp] * NL, [None] + P["bias"][1:],
+                    hs, Hp, cs, gates, cstate, zero_padded_k=True, tag="enc_lstm_fwd", add_table=tbl, add_index=idx)
         # K3: conv stack over the hidden axis, sequence position = channel (models.py:129-131)
         c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
         k = c1.kernel_size
