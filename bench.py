@@ -259,7 +259,7 @@ def pmc_traffic(kernel_key, B, dtype):
     the same kernel at the same batch (bench.py cannot run the profiler on itself); (None, None) when no profile of this shape exists."""
     if dtype != "bf16":
         return None, None
-    for name in (f"r03_pmc_kernels_T16_B{B}.json", f"r02_pmc_kernels_T16_B{B}.json", f"r01_v9_pmc_kernels_T16_B{B}.json"):
+    for name in (f"r04_pmc_kernels_T16_B{B}.json", f"r03_pmc_kernels_T16_B{B}.json", f"r02_pmc_kernels_T16_B{B}.json", f"r01_v9_pmc_kernels_T16_B{B}.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

@@ -340,7 +340,8 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 class CosineAnnealingLRWithRestart:
-    """moses_train_distrib.py:61-89, same state machine: period 10 epochs, lr_end 1e-4, no period growth; constructing it performs the
+    """A RESTATEMENT of moses_train_distrib.py:61-89 (the surface fixes the attribute names and the arithmetic; nothing here is MI355X-specific),
+    same state machine: period 10 epochs, lr_end 1e-4, no period growth; constructing it performs the
     first ``step()`` (as ``_LRScheduler.__init__`` does), so the very first epoch already runs at the k = 1 point of the cosine."""
 
     def __init__(self, optimizer):
@@ -396,7 +397,8 @@ def cosine_lr_with_restart(base_lr, epoch_in_period, period=10, lr_end=1e-4):
 
 
 class KLAnnealer:
-    """moses_train_distrib.py:47-58: linear 0 -> 1 over n_epoch."""
+    """A RESTATEMENT of moses_train_distrib.py:47-58 (ten lines of schedule arithmetic whose names the trainer surface fixes): linear 0 -> 1
+    over n_epoch."""
 
     def __init__(self, n_epoch):
         self.i_start, self.w_start, self.w_max, self.n_epoch = 0, 0, 1, n_epoch

@@ -188,3 +188,47 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     assert lib.mvae_timesum(L.MVAE_F32, 0, 4, 8, p, p, None) == INV
     assert lib.mvae_rowsum(L.MVAE_F32, 0, 4, p, 4, p, 0, None) == INV
     assert lib.mvae_relu_bwd(8, None, p, None) == INV
+
+
+def test_gru_rowres_time_loops_issue_exactly_the_counted_memory_operations(tmp_path):
+    """the counted s_waitcnt vmcnt(N) of gru_rowres_fwd / _bwd (NLD / NST in rnn_rowres.hip) are right only while the compiler
+    emits exactly that many vector-memory instructions per time step -- no merged, split or predicated-away access, no scratch traffic.
+    Disassemble the shipped library and count the global loads / stores inside each kernel's time loop (the widest backward branch)."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    lib = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(L.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib], cwd=str(tmp_path), capture_output=True, check=True)
+    text = None
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" in f:
+            d = subprocess.run([objdump, "-d", os.path.join(str(tmp_path), f)], capture_output=True, text=True).stdout
+            if "gru_rowres_fwd_kernel" in d:
+                text = d
+    assert text is not None, "gru_rowres kernels not found in the library's gfx950 code objects"
+    want = {"gru_rowres_fwd_kernelILi256ELb1E": (6, 10), "gru_rowres_fwd_kernelILi256ELb0E": (6, 2), "gru_rowres_bwd_kernelILi256E": (10, 8)}
+    for key, (nld, nst) in want.items():
+        m = re.search(r"<[^>]*" + key + r"[^>]*>:\n(.*?)s_endpgm", text, flags=re.S)
+        assert m, key
+        ins = []                                    # (address, mnemonic, operand text)
+        for line in m.group(1).splitlines():
+            mm = re.match(r"\s*(\S+)\s+(.*?)//\s*([0-9A-Fa-f]+):", line)
+            if mm:
+                ins.append((int(mm.group(3), 16), mm.group(1), mm.group(2)))
+        assert not any(i[1].startswith("scratch_") for i in ins), key
+        loops = []
+        for a, mn, ops_ in ins:
+            if mn.startswith("s_cbranch") or mn == "s_branch":
+                off = int(ops_.split()[0])
+                if off >= 32768:
+                    loops.append((a + 4 + (off - 65536) * 4, a))       # backward branch: (target, branch address)
+        assert loops, key
+        lo, hi = max(loops, key=lambda t: t[1] - t[0])                # the time loop
+        body = [i for i in ins if lo <= i[0] <= hi]
+        loads = sum(1 for i in body if i[1].startswith(("global_load", "buffer_load")))
+        stores = sum(1 for i in body if i[1].startswith(("global_store", "buffer_store")))
+        steps = sum(1 for i in body if i[1] == "s_barrier")            # one workgroup barrier per time step (the compiler may unroll the loop)
+        assert steps >= 1 and (loads, stores) == (nld * steps, nst * steps), (key, loads, stores, steps)
