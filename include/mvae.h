@@ -207,7 +207,10 @@ typedef struct {
    * 4 layers, H = 1024, B = 128, zero initial state, time-invariant layer-0 input, ldh = H + 64, a 256-CU device with nothing else running
    * beside it): mvae_rnn_fwd_persist_workspace() returns 0 for everything else.  persist_ws != NULL (that many bytes of device memory,
    * 16-byte aligned) selects it; the first 16 bytes are a status record the launch leaves behind -- word 0 != 0: a bounded spin ran out
-   * (a workgroup was not resident, or a producer died), the outputs are invalid; the launch itself always ends. */
+   * (a workgroup was not resident, or a producer died), the outputs are invalid; the launch itself always ends.
+   * The narrow exact-f32 stacks (LSTM, H = 72: the encoder, models.py:117,128) use the same scratch for their LAYER-CONCURRENT row-resident form
+   * (rnn_rowres.hip: all layers in one launch as a pipeline over per-workgroup progress words, when layers x ceil(B / 4) workgroups are resident
+   * at once); same status convention. */
   void* persist_ws; size_t persist_ws_bytes;
 } mvae_rnn_fwd_desc;
 

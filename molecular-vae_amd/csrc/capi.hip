@@ -77,10 +77,14 @@ int mvae_dropout_keep(uint32_t seed, uint32_t idx, float p) {
 }
 
 int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) {
-  if (d && d->persist_ws) return rnn_persist_fwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream);   // refuses shapes it does not serve
-  return rnn_fwd_impl(d, (hipStream_t)stream);
+  if (d && d->persist_ws && rnn_persist_fwd_supported(d)) return rnn_persist_fwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream);
+  return rnn_fwd_impl(d, (hipStream_t)stream);      // (the row-resident f32 stacks use persist_ws for their layer-concurrent form)
 }
-size_t mvae_rnn_fwd_persist_workspace(const mvae_rnn_fwd_desc* d) { return (d && rnn_persist_fwd_supported(d)) ? rnn_persist_fwd_workspace_bytes(d->T) : 0; }
+size_t mvae_rnn_fwd_persist_workspace(const mvae_rnn_fwd_desc* d) {
+  if (!d) return 0;
+  if (rnn_persist_fwd_supported(d)) return rnn_persist_fwd_workspace_bytes(d->T);
+  return rnn_rowres_fwd_pipe_workspace(d);
+}
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d) { return rnn_bwd_workspace_bytes(d); }
 

@@ -64,8 +64,13 @@ struct RowResF {
 
 constexpr int RR_TBL_ROWS = 64, RR_TBL_T = 256;      // LDS table / id capacity of the TBL form
 
-template <int H, bool HASX, int NTHR, bool TBL = false>
-__global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
+// Pipeline context of the layer-concurrent forms: `above` = progress word of the workgroup that produces our input (same batch rows, the
+// neighbouring layer; nullptr: the input is complete), `mine` = our own progress word (nullptr: nobody consumes our output inside the launch).
+// Forward: progress = number of completed time steps; hs[t] is visible once progress >= t + 1.
+struct RowPipe { const uint32_t* above; uint32_t* mine; uint32_t* status; uint32_t spin_limit; };
+
+template <int H, bool HASX, int NTHR, bool TBL = false, bool PIPE = false>
+__device__ __forceinline__ void lstm_rowres_fwd_body(const RowResF& p, int rowgroup, RowPipe pp) {
   constexpr int G4 = 4 * H, K = (HASX ? 2 * H : H), KW = K / 4, NG = (G4 + 63) / 64, NA = (KW + 15) / 16;
   constexpr int KPAD = 2 * H + 8, NPAD = NG * 64;
   static_assert(K % 4 == 0 && (KPAD % 32) == 24, "K-slices per wave; A-buffer rows on disjoint banks");
@@ -76,7 +81,25 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
   __shared__ float tblS[TBL ? RR_TBL_ROWS * G4 : 1];
   __shared__ int idS[TBL ? RR_ROWS * RR_TBL_T : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * RR_ROWS, B = p.B, T = p.T;
+  const int r0 = rowgroup * RR_ROWS, B = p.B, T = p.T;
+  uint32_t known = 0;
+  auto wait_above = [&](uint32_t need) {          // PIPE: bounded poll of the producer's progress word (see rowres_bwd_layer)
+    if (!PIPE || pp.above == nullptr || known >= need) return;
+    for (uint32_t it = 0; it < pp.spin_limit; ++it) {
+      known = __hip_atomic_load(pp.above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (known >= need) return;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (pp.status) atomicCAS(pp.status, 0u, 3u);
+    known = 0xffffffffu;
+  };
+  auto load_x = [&](const float* src) -> float4 {  // the layer below's h: agent-scope loads in the pipelined form (not through this CU's L1)
+    if (!PIPE) return *reinterpret_cast<const float4*>(src);
+    float4 v;
+    v.x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
   if (TBL) {
     for (int i = tid; i < p.tbl_rows * G4; i += NTHR) tblS[i] = p.tbl[i];
     for (int i = tid; i < RR_ROWS * T; i += NTHR) {
@@ -122,7 +145,8 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
   const int xr = tid / (H / 4), xc = (tid % (H / 4)) * 4;       // x prefetch: thread -> (row, 4 columns), tid < 4 * H / 4
   const bool xload = HASX && tid < RR_ROWS * (H / 4) && r0 + xr < B;
   float4 xpre = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (xload) xpre = *reinterpret_cast<const float4*>(p.x + ((long)(r0 + xr)) * p.ldx + xc);
+  if (HASX) wait_above(1u);                       // x_0 = the layer below's step 0
+  if (xload) xpre = load_x(p.x + ((long)(r0 + xr)) * p.ldx + xc);
   if (HASX && tid < RR_ROWS * (H / 4)) *reinterpret_cast<float4*>(&abuf[0][xr][xc]) = xpre;
   auto load_add = [&](int t) {
 #pragma unroll
@@ -147,7 +171,8 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
     // prefetch x_{t+1} (the gate phase stores it into the next A buffer)
-    if (xload && t + 1 < T) xpre = *reinterpret_cast<const float4*>(p.x + ((long)(t + 1) * B + r0 + xr) * p.ldx + xc);
+    if (HASX && t + 1 < T) wait_above((uint32_t)(t + 2));
+    if (xload && t + 1 < T) xpre = load_x(p.x + ((long)(t + 1) * B + r0 + xr) * p.ldx + xc);
     // ---- MFMA phase
     if (wave < 4) {
       float areg[NA];
@@ -165,7 +190,9 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
 #pragma unroll
         for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     }
+    if (PIPE && pp.mine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous step's h stores (a whole MFMA phase old) are out
     rr_barrier();
+    if (PIPE && pp.mine && tid == 0 && t > 0) __hip_atomic_store(pp.mine, (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // steps 0 .. t - 1 complete
     // ---- gate phase.  x_{t+1} (requested before the MFMA phase) goes into the next A buffer first: behind this step's stores the wait
     // for it would also wait for their write acknowledgements
     if (HASX && tid < RR_ROWS * (H / 4)) *reinterpret_cast<float4*>(&abuf[nxt][xr][xc]) = xpre;
@@ -186,7 +213,8 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
       abuf[nxt][row][(HASX ? H : 0) + u] = h;
       if (r0 + row < B) {
         const long o = (long)t * B + r0 + row;
-        p.hs[o * p.ldh + u] = h;
+        if (PIPE) __hip_atomic_store(p.hs + o * p.ldh + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through: the layer above reads it inside this launch
+        else p.hs[o * p.ldh + u] = h;
         p.cs[o * H + u] = c;
         float* g4 = p.gates + o * G4 + u;
         g4[0] = gi; g4[H] = gf; g4[2 * H] = gg; g4[3 * H] = go;
@@ -195,6 +223,32 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
     if ((TBL || p.add) && t + 1 < T) load_add(t + 1);
     rr_barrier();
   }
+  if (PIPE && pp.mine) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(pp.mine, (uint32_t)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int H, bool HASX, int NTHR, bool TBL = false>
+__global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
+  lstm_rowres_fwd_body<H, HASX, NTHR, TBL, false>(p, blockIdx.x, RowPipe{nullptr, nullptr, nullptr, 0});
+}
+
+// All layers as CONCURRENT workgroups (round 4; see lstm_rowres_bwd_pipe_kernel): workgroup (l, g) runs layer l for batch rows 4 g .. 4 g + 3
+// and reads the h_t that workgroup (l - 1, g) stored a step or two earlier.  Layer 0 (token table in LDS) first in the grid.  The launcher
+// uses this form only when every workgroup of the grid is resident at once.
+struct RowResFAll { RowResF l[MVAE_MAX_LAYERS]; int nl; };
+template <int H, bool TBL0>
+__global__ __launch_bounds__(320) void lstm_rowres_fwd_pipe_kernel(RowResFAll a, uint32_t* flags, uint32_t* status, uint32_t spin_limit) {
+  const int nblk = gridDim.x / a.nl;
+  const int l = (int)(blockIdx.x / nblk), g = (int)(blockIdx.x % nblk);
+  RowPipe pp;
+  pp.above = (l > 0) ? flags + (l - 1) * nblk + g : nullptr;
+  pp.mine = (l + 1 < a.nl) ? flags + l * nblk + g : nullptr;
+  pp.status = status; pp.spin_limit = spin_limit;
+  if (l == 0) lstm_rowres_fwd_body<H, false, 320, TBL0, true>(a.l[0], g, pp);
+  else lstm_rowres_fwd_body<H, true, 320, false, true>(a.l[l], g, pp);
 }
 
 // ---------------------------------------------------------------------------------------------------------- backward
@@ -216,13 +270,30 @@ struct RowResBAll { RowResB l[MVAE_MAX_LAYERS]; int nl; };
 // One launch keeps the 128 workgroups resident for the whole pass: they do not have to win their CUs back from concurrently
 // running GEMM workgroups at every layer boundary.  Layer 0 has no input gradient (hasx = false: zero W_ih fragments, no dx stores).
 // HASX = false (layer 0: no input gradient): the MFMA output is dh_rec alone -- H columns = 2 groups of 64 instead of 3, a third fewer MFMAs.
-template <int H, int NTHR, bool HASX>
-__device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)[RR_ROWS][4 * H + 24], float (&red)[4][RR_ROWS][192]) {
+// (RowPipe, backward: `above` = progress word of the workgroup that produces our dy -- the layer above, same batch rows --, progress = number
+// of completed time steps, T + 1 once dx[0] is out: dx[s] is visible once progress >= T - s + 1)
+template <int H, int NTHR, bool HASX, bool PIPE = false>
+__device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)[RR_ROWS][4 * H + 24], float (&red)[4][RR_ROWS][192], int rowgroup,
+                                                 RowPipe pp = RowPipe{nullptr, nullptr, nullptr, 0}) {
   constexpr int G4 = 4 * H, KW = H, NOUT = HASX ? 2 * H : H, NG = (NOUT + 63) / 64, NA = (KW + 15) / 16;
   constexpr int GPAD = G4 + 24, NPAD = NG * 64, RO = HASX ? H : 0;       // RO: column of dh_rec inside the MFMA output
   static_assert((GPAD % 32) == 24 && NPAD <= 192, "A-buffer rows on disjoint banks");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * RR_ROWS, B = p.B, T = p.T;
+  const int r0 = rowgroup * RR_ROWS, B = p.B, T = p.T;
+  // PIPE: wait (bounded) until the producer of our dy has completed `need` steps; every thread polls for itself (it then loads its own dy
+  // elements with agent-scope loads), and only when its last look at the word does not cover the request -- a consumer that has fallen a few
+  // steps behind polls once for several steps
+  uint32_t known = 0;
+  auto wait_above = [&](uint32_t need) {
+    if (!PIPE || pp.above == nullptr || known >= need) return;
+    for (uint32_t it = 0; it < pp.spin_limit; ++it) {
+      known = __hip_atomic_load(pp.above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (known >= need) return;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (pp.status) atomicCAS(pp.status, 0u, 2u);          // gave up: the results are invalid, the launch still ends
+    known = 0xffffffffu;
+  };
   float W[NG][KW];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -250,7 +321,8 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
         const float* g4 = p.gates + o * G4 + u;
         gt[it][0] = g4[0]; gt[it][1] = g4[H]; gt[it][2] = g4[2 * H]; gt[it][3] = g4[3 * H];
         c_prev[it] = (t > 0) ? p.cs[(o - B) * H + u] : 0.f;
-        dyv[it] = p.dy[o * p.dy_ld + u];
+        if (PIPE) dyv[it] = __hip_atomic_load(p.dy + o * p.dy_ld + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // sc1: not through this CU's L1
+        else dyv[it] = p.dy[o * p.dy_ld + u];
       }
     }
   };
@@ -262,6 +334,7 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
     for (int g = 0; g < 4; ++g) gt[it][g] = 0.f;
     if (id < NITEM && r0 + row < B) c_cur[it] = p.cs[((long)(T - 1) * B + r0 + row) * H + u];
   }
+  wait_above(2u);                                                    // dy[T - 1] = the producer's dx[T - 1]: out after its first two steps
   prefetch(T - 1);
   for (int t = T - 1; t >= 0; --t) {
     // ---- gate phase
@@ -271,6 +344,7 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
     if (t > 0) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) c_cur[it] = c_prev[it];      // c_{t-1} is the next step's cell state
+      wait_above((uint32_t)(T - t + 2));                             // dy[t - 1]
       prefetch(t - 1);                                               // in flight under this step's math and MFMAs
     }
 #pragma unroll
@@ -280,8 +354,11 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
       float dh = dyt[it];
       if (t < T - 1) {
         dh += (red[0][row][RO + u] + red[1][row][RO + u]) + (red[2][row][RO + u] + red[3][row][RO + u]);
-        if (HASX && r0 + row < B)
-          p.dx[((long)(t + 1) * B + r0 + row) * H + u] = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
+        if (HASX && r0 + row < B) {
+          const float v = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
+          if (PIPE) __hip_atomic_store(p.dx + ((long)(t + 1) * B + r0 + row) * H + u, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+          else p.dx[((long)(t + 1) * B + r0 + row) * H + u] = v;
+        }
       }
       const float tc = tanh_fast(cc[it]);
       const float d_o = dh * tc;
@@ -315,13 +392,24 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
 #pragma unroll
         for (int i = 0; i < RR_ROWS; ++i) red[wave][i][64 * g + lane] = C[g][i];
     }
+    if (PIPE && pp.mine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's dx stores (issued a whole MFMA phase ago) are out
     rr_barrier();
+    if (PIPE && pp.mine && tid == 0) __hip_atomic_store(pp.mine, (uint32_t)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (HASX) {                                                       // input gradient of step 0
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = tid + it * NTHR, row = id / H, u = id % H;
-      if (id < NITEM && r0 + row < B) p.dx[((long)(r0 + row)) * H + u] = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
+      if (id < NITEM && r0 + row < B) {
+        const float v = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
+        if (PIPE) __hip_atomic_store(p.dx + ((long)(r0 + row)) * H + u, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p.dx[((long)(r0 + row)) * H + u] = v;
+      }
+    }
+    if (PIPE && pp.mine) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(pp.mine, (uint32_t)(T + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -332,10 +420,29 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) 
   __shared__ float gbuf[RR_ROWS][4 * H + 24];         // dG_t of the 4 rows (A operand)
   __shared__ float red[4][RR_ROWS][192];
   for (int l = a.nl - 1; l >= 0; --l) {
-    if (l > 0) rowres_bwd_layer<H, 256, true>(a.l[l], gbuf, red);
-    else rowres_bwd_layer<H, 256, false>(a.l[l], gbuf, red);
+    if (l > 0) rowres_bwd_layer<H, 256, true>(a.l[l], gbuf, red, blockIdx.x);
+    else rowres_bwd_layer<H, 256, false>(a.l[l], gbuf, red, blockIdx.x);
     if (l > 0) { __threadfence(); __syncthreads(); }  // our dx rows are visible to the loads of the next layer; gbuf / red are free again
   }
+}
+
+// The same layers as CONCURRENT workgroups (round 4): workgroup (l, g) runs layer l for batch rows 4 g .. 4 g + 3 and consumes the input
+// gradient dx[t] that workgroup (l + 1, g) produced a couple of steps earlier -- a pipeline over the layers with one progress word per
+// workgroup (write-through dx stores, drained before the step's second barrier; agent-scope dy loads; bounded polls) instead of one layer
+// after the other: the pass takes ~T + 2 (layers - 1) steps instead of layers x T.  The top layer comes first in the grid (dispatch order is
+// not promised: the launcher only uses this form when EVERY workgroup of the grid is resident at once, so nobody waits for a queued one).
+template <int H>
+__global__ __launch_bounds__(256) void lstm_rowres_bwd_pipe_kernel(RowResBAll a, uint32_t* flags, uint32_t* status, uint32_t spin_limit) {
+  __shared__ float gbuf[RR_ROWS][4 * H + 24];
+  __shared__ float red[4][RR_ROWS][192];
+  const int nblk = gridDim.x / a.nl;
+  const int l = a.nl - 1 - (int)(blockIdx.x / nblk), g = (int)(blockIdx.x % nblk);
+  RowPipe pp;
+  pp.above = (l + 1 < a.nl) ? flags + (l + 1) * nblk + g : nullptr;
+  pp.mine = (l > 0) ? flags + l * nblk + g : nullptr;
+  pp.status = status; pp.spin_limit = spin_limit;
+  if (l > 0) rowres_bwd_layer<H, 256, true, true>(a.l[l], gbuf, red, g, pp);
+  else rowres_bwd_layer<H, 256, false, true>(a.l[l], gbuf, red, g, pp);
 }
 
 // =====================================================================================================================
@@ -704,6 +811,15 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
 }  // namespace
 
 // layers of one pass, sequentially; returns MVAE_ERR_UNSUPPORTED when the shape is not the one this schedule is built for
+// scratch of the layer-concurrent forward (0: the shape / device is not served by it): [status 16 words | layers x ceil(B / 4) progress words]
+size_t rnn_rowres_fwd_pipe_workspace(const mvae_rnn_fwd_desc* d) {
+  if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != 72 || d->x0 || d->lengths || d->layers < 2 || !d->gates[0]) return 0;
+  const int nblk = (d->B + RR_ROWS - 1) / RR_ROWS;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || d->layers * nblk > cus) return 0;
+  return ((size_t)d->layers * nblk + 16) * sizeof(uint32_t);
+}
+
 int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   constexpr int H = 72;
   if (d->cell != MVAE_CELL_LSTM || d->dtype != MVAE_F32 || d->H != H || d->x0 || d->lengths) return MVAE_ERR_UNSUPPORTED;
@@ -719,6 +835,40 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   // B = 1024: 0.575 -> 0.790 ms, the two [T*B, 72] x [72, 288] GEMMs then cost more than the halved contraction saves)
   const char* hv = mvae_knob("MVAE_ROWRES_HOIST");
   const bool hoist = hv ? atoi(hv) != 0 : (long)T * B <= 16384;
+  // Layer-concurrent form (one launch, the layers as a pipeline over progress words): when every workgroup of the grid is resident at once
+  // (one per CU is what is assumed) and the caller gave scratch for the progress words (persist_ws: layers x ceil(B / 4) + 16 words).  It
+  // replaces the hoisted form too: 0.427 ms (hoisted, layer after layer) -> see DESIGN.md at b = 128.
+  {
+    const int nblk = (B + RR_ROWS - 1) / RR_ROWS, NL = d->layers;
+    int dev = 0, cus = 0;
+    const char* pk = mvae_knob("MVAE_ROWRES_PIPE");
+    bool pipe = (pk ? atoi(pk) != 0 : true) && NL >= 2 && d->persist_ws && d->persist_ws_bytes >= ((size_t)NL * nblk + 16) * sizeof(uint32_t);
+    if (pipe && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || NL * nblk > cus)) pipe = false;
+    for (int l = 1; l < NL && pipe; ++l) if (reinterpret_cast<uintptr_t>(d->hs[l - 1]) & 15) pipe = false;
+    if (pipe) {
+      RowResFAll all;
+      all.nl = NL;
+      for (int l = 0; l < NL; ++l) {
+        RowResF& a = all.l[l];
+        a.x = l ? reinterpret_cast<const float*>(d->hs[l - 1]) : nullptr; a.ldx = d->ldh;
+        a.add = l ? nullptr : d->add0; a.add_ts = d->add0_tstride;
+        a.tbl = d->add_table; a.tbl_rows = d->add_table_rows; a.idx = d->add_index; a.idx_ld = d->add_index_ld;
+        a.w_ih = l ? reinterpret_cast<const float*>(d->w_ih[l]) : nullptr; a.ldw_ih = d->ldw_ih[l];
+        a.w_hh = reinterpret_cast<const float*>(d->w_hh[l]); a.ldw_hh = d->ldw_hh[l];
+        a.bias = d->bias[l];
+        a.hs = reinterpret_cast<float*>(d->hs[l]); a.ldh = d->ldh;
+        a.cs = reinterpret_cast<float*>(d->cs[l]); a.gates = reinterpret_cast<float*>(d->gates[l]);
+        a.T = T; a.B = B;
+      }
+      uint32_t* status = reinterpret_cast<uint32_t*>(d->persist_ws);       // [status 16 words | progress words]: the host reads the first 16 bytes
+      uint32_t* flags = status + 16;
+      MVAE_CHECK_HIP(hipMemsetAsync(status, 0, ((size_t)NL * nblk + 16) * sizeof(uint32_t), st));
+      if (tbl) hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, true>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, 1u << 20);
+      else hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, false>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, 1u << 20);
+      MVAE_CHECK_HIP(hipGetLastError());
+      return MVAE_OK;
+    }
+  }
   for (int l = 0; l < d->layers; ++l) {
     RowResF a;
     a.x = l ? reinterpret_cast<const float*>(d->hs[l - 1]) : nullptr; a.ldx = d->ldh;
@@ -750,7 +900,10 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   return MVAE_OK;
 }
 
-size_t rnn_rowres_bwd_workspace(int layers, int T, int B, int H) { return (H == 72 && layers > 1) ? (size_t)2 * T * B * H * sizeof(float) : 0; }
+// [dx ping | dx pong | progress words layers x ceil(B / 4) + status (pipelined form)]
+size_t rnn_rowres_bwd_workspace(int layers, int T, int B, int H) {
+  return (H == 72 && layers > 1) ? (size_t)2 * T * B * H * sizeof(float) + ((size_t)layers * ((B + RR_ROWS - 1) / RR_ROWS) + 16) * sizeof(uint32_t) : 0;
+}
 
 // top layer first; layer l's input gradient (dx, scratch ping-pong) is layer l-1's dy
 int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
@@ -776,7 +929,21 @@ int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     a.T = T; a.B = B;
     dy = a.dx; dy_ld = H;
   }
-  hipLaunchKernelGGL((lstm_rowres_bwd_all_kernel<H>), dim3((B + RR_ROWS - 1) / RR_ROWS), dim3(256), 0, st, all);
+  // layer-concurrent form: every workgroup of the grid must be resident at once (one per CU is what is assumed), 2 or 3 layers (the dx
+  // ping-pong has two buffers: layer l writes l & 1 while layer l + 2 writes the same one only when there are four)
+  const int nblk = (B + RR_ROWS - 1) / RR_ROWS;
+  int dev = 0, cus = 0;
+  const char* pk = mvae_knob("MVAE_ROWRES_PIPE");
+  bool pipe = (pk ? atoi(pk) != 0 : true) && NL >= 2 && NL <= 3;
+  if (pipe && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || NL * nblk > cus)) pipe = false;
+  uint32_t* flags = need ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d->split_ws) + (size_t)2 * T * B * H * sizeof(float)) : nullptr;
+  uint32_t* status = flags ? flags + (size_t)NL * nblk : nullptr;
+  if (flags) MVAE_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)NL * nblk + 16) * sizeof(uint32_t), st));     // progress words + status (the host reads the status in either form)
+  if (pipe && flags) {
+    hipLaunchKernelGGL((lstm_rowres_bwd_pipe_kernel<H>), dim3(NL * nblk), dim3(256), 0, st, all, flags, status, 1u << 20);
+  } else {
+    hipLaunchKernelGGL((lstm_rowres_bwd_all_kernel<H>), dim3(nblk), dim3(256), 0, st, all);
+  }
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

@@ -509,7 +509,7 @@ def dropout_keep_mask(seed, shape_lt_b_h, p):
 # else held a CU): it then leaves a status record, which is copied to pinned host memory behind the launch and checked at the next call
 # and by persist_check().
 PERSIST_DEFAULT = "1"
-PERSIST_STATS = {"launches": 0}     # how many passes took the persistent schedule (tests / logs)
+PERSIST_STATS = {"launches": 0, "rowres_pipe": 0}     # passes that took the persistent decoder schedule / the layer-concurrent encoder form (tests / logs)
 _PERSIST_PENDING = []      # [(pinned int32[4], event, what)]
 
 
@@ -581,7 +581,7 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
     with _Timed(tag):
         check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
     if pws is not None:
-        PERSIST_STATS["launches"] += 1
+        PERSIST_STATS["launches" if dtype == torch.bfloat16 else "rowres_pipe"] += 1
         host = torch.empty(4, dtype=torch.int32, pin_memory=True)
         host.copy_(pws[:16].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event(); ev.record()
@@ -629,6 +629,16 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     d.split_ws, d.split_ws_bytes = sws.data_ptr(), need
     with _Timed(tag):
         check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr()), "mvae_rnn_bwd")
+    if cell == L.CELL_LSTM and dtype == torch.float32 and H == 72 and 2 <= NL <= 3 and need:
+        # the layer-concurrent row-resident backward (rnn_rowres.hip) polls progress words with BOUNDED spins; its status word sits behind
+        # them in the workspace: [2 x T x B x H fp32 | NL x ceil(B / 4) words | status] -- checked like the persistent forward's
+        off = 2 * T * B * H * 4 + NL * ((B + 3) // 4) * 4
+        if off + 16 <= need:
+            persist_check()
+            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            host.copy_(sws[off:off + 16].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            _PERSIST_PENDING.append((host, ev, tag or "mvae_rnn_bwd (row-resident, layer-concurrent)"))
 
 
 def sumsq(g, partial):

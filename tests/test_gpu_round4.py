@@ -403,9 +403,9 @@ def test_persistent_dataflow_failed_hand_off_is_reported_not_hung(monkeypatch):
 
 
 def test_persistent_schedule_inside_the_training_step_b128(golden_dir):
-    """The product path at the per-rank batch of the 8-GPU configuration takes the persistent forward by default; against the same model with
-    the schedule switched off: loss within 1e-4, mu / logvar identical (the encoder does not change), every parameter gradient within the
-    bf16 tolerance of the fixture tests."""
+    """The product path at the per-rank batch of the 8-GPU configuration takes the persistent decoder forward (and the layer-concurrent encoder
+    passes) by default; against the same model with the schedules switched off: loss within 1e-4, mu within 2e-6, every parameter gradient
+    within the bf16 tolerance of the fixture tests."""
     g = np.load(os.path.join(golden_dir, "g2_full.npz"))
     params = ip.init_params(ip.molvae_shapes(), 202, 1.5, np.float32)
     rep = 32
@@ -439,7 +439,9 @@ def test_persistent_schedule_inside_the_training_step_b128(golden_dir):
     assert out["1"][3] == 2 and out["0"][3] == 0
     assert float((out["1"][4] - out["0"][4]).abs().max()) < 2e-3          # evaluation (forward-only form) reconstructions
     assert abs(out["1"][0] - out["0"][0]) < 1e-4 * abs(out["0"][0]) and abs(out["1"][0] - float(g["loss"])) < 1e-4 * float(g["loss"])
-    assert torch.equal(out["1"][1], out["0"][1])
+    # (the switch also selects the encoder's layer-concurrent row-resident form, whose layers >= 1 contract [x | h] in one chain instead of
+    # adding a hoisted input projection: exact-f32 re-association, ~1e-7)
+    assert rel(out["1"][1].cpu().numpy(), out["0"][1].cpu().numpy()) < 2e-6
     bad = {k: rel(out["1"][2][k].cpu().numpy(), out["0"][2][k].cpu().numpy()) for k in out["1"][2]
            if rel(out["1"][2][k].cpu().numpy(), out["0"][2][k].cpu().numpy()) > 5e-2}
     assert not bad, bad
@@ -507,3 +509,45 @@ def test_moses_sample_is_reproducible_from_its_seed_and_launches_four_kernels_pe
     assert per_token == 25
     steps = sum(1 for n_ in names if "gru_step" in n_ or "lstm_step" in n_ or "step_fwd" in n_)
     assert steps == 3 * 25, (steps, sorted(set(names)))
+
+
+@pytest.mark.parametrize("B", [8, 128, 200])
+def test_layer_concurrent_row_resident_encoder_passes_equal_the_layer_by_layer_form(B, monkeypatch):
+    """rnn_rowres.hip, round 4: the encoder LSTM(72) x 3 forward and backward as ONE launch each with the layers running concurrently (a
+    pipeline over per-workgroup progress words, agent-scope stores / loads of the hand-off rows, bounded polls) against the layer-after-layer
+    launches (MVAE_ROWRES_PIPE=0, input projection not hoisted so that both add the same products in the same order): outputs, saved state
+    and every pre-activation gradient agree to exact-f32 rounding (the two forms are separate instantiations: the compiler's fma contraction
+    may differ by an ulp, 4e-8 observed), for a batch that is not a multiple of the 4 rows a workgroup owns too."""
+    from molecular_vae_amd import _lib as L
+    T, H, NL, Hp, G4 = 120, 72, 3, 96, 288
+    g = torch.Generator(device="cuda").manual_seed(B)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.2
+    Wih = [None] + [torch.zeros(G4, Hp, device=dev) for _ in range(NL - 1)]
+    Whh = [torch.zeros(G4, Hp, device=dev) for _ in range(NL)]
+    for w in Wih[1:] + Whh:
+        w[:, :H] = rnd(G4, H)
+    WihT = [None] + [w[:, :H].t().contiguous() for w in Wih[1:]]
+    WhhT = [w[:, :H].t().contiguous() for w in Whh]
+    bias = [None] + [rnd(G4) for _ in range(NL - 1)]
+    tbl = rnd(35, G4)
+    idx = torch.randint(0, 35, (B, T), device=dev, generator=g)
+    dy = rnd(T, B, H)
+
+    def run(pipe):
+        monkeypatch.setenv("MVAE_ROWRES_PIPE", pipe)
+        monkeypatch.setenv("MVAE_ROWRES_HOIST", "0")
+        b = dict(hs=[torch.zeros(T, B, Hp, device=dev) for _ in range(NL)], cs=[torch.zeros(T, B, H, device=dev) for _ in range(NL)],
+                 gates=[torch.zeros(T, B, G4, device=dev) for _ in range(NL)], cstate=[torch.zeros(2, B, H, device=dev) for _ in range(NL)],
+                 dG=[torch.zeros(T, B, G4, device=dev) for _ in range(NL)], dstate=[torch.zeros(2, B, H, device=dev) for _ in range(NL)])
+        ops.rnn_fwd(L.CELL_LSTM, torch.float32, T, B, H, None, 0, Wih, [Hp] * NL, Whh, [Hp] * NL, bias, b["hs"], Hp, b["cs"], b["gates"], b["cstate"],
+                    zero_padded_k=True, add_table=tbl, add_index=idx, persist=(pipe == "1"))
+        ops.rnn_bwd(L.CELL_LSTM, torch.float32, T, B, H, WhhT, [G4] * NL, WihT, [G4] * NL, dy, H, b["hs"], Hp, b["cs"], b["gates"], b["dG"], b["dstate"])
+        torch.cuda.synchronize()
+        ops.persist_check(sync=True)
+        return b
+    n0 = ops.PERSIST_STATS["rowres_pipe"]
+    a, p = run("0"), run("1")
+    assert ops.PERSIST_STATS["rowres_pipe"] == n0 + 1
+    for k, tol in (("hs", 2e-6), ("cs", 2e-6), ("gates", 2e-6), ("dG", 2e-5)):
+        for l in range(NL):
+            assert rel(a[k][l].cpu().numpy(), p[k][l].cpu().numpy()) < tol, (k, l, float((a[k][l] - p[k][l]).abs().max()))
