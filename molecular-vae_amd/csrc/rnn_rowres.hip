@@ -474,6 +474,7 @@ struct GruRowF {
   bf16_t* gates;                     // out [T][B][4H] (r, z, n, W_hn h + b_hn) or nullptr
   float* hstate;                     // out [2][B][H]: slot (T - 1) & 1 receives the final state
   int T, B;
+  int safe;                          // != 0 (MVAE_GRU_ROWRES_SAFE, tests): every counted wait becomes vmcnt(0) -- the reference form the counted one must equal bit for bit
 };
 
 // Loads of the time loops as inline asm: the compiler's wait-count pass loses the exact queue state at a loop's back edge and drains the
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(512) void gru_rowres_fwd_kernel(GruRowF p) {
     const uint32_t ab = a_lane + (uint32_t)(cur * GR_ROWS * LDA * 2);
     u32x4 af[2], wn[2][UT];
     gru_frag_step<0, KBLK, UT>(af, wn, ab, wn_lane, wf, acc);
+    if (p.safe) wait_vmcnt<0>(); else
     wait_vm_case<NLD, NST>(t + 1 < T, t > 0);                 // this step's table rows have arrived
 #pragma unroll
     for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(gx[i][0][0]), "+v"(gx[i][0][1]), "+v"(gx[i][1][0]), "+v"(gx[i][1][1]), "+v"(gx[i][2][0]), "+v"(gx[i][2][1]));
@@ -667,6 +669,7 @@ struct GruRowB {
   const int* lengths;
   bf16_t* dG; long ldg;              // out [T][B][ldg], 4 slots
   int T, B;
+  int safe;                          // as GruRowF::safe
 };
 constexpr int GRB_LDG = 3 * 256 + 8;
 
@@ -762,6 +765,7 @@ __global__ __launch_bounds__(512) void gru_rowres_bwd_kernel(GruRowB p) {
     u32x4 af[2], wl[2][UT];
     af[0] = lds_read128<0>(ab);
     GruFragB<0, NREG, NK, UT>::run(af, wl, ab, wl_lane, wf, acc);
+    if (p.safe) wait_vmcnt<0>(); else
     wait_vm_case<NLD, NST>(t > 0, k > 0);                     // this step's operands have arrived
 #pragma unroll
     for (int j = 0; j < UT; ++j) asm volatile("" : "+v"(o.g[j][0]), "+v"(o.g[j][1]), "+v"(o.g[j][2]), "+v"(o.g[j][3]), "+v"(o.hp[j]));
@@ -957,6 +961,7 @@ int rnn_gru_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
   if ((long)d->T * d->B * 4 * H >= (1L << 31) || (long)d->T * d->B * d->ldh >= (1L << 31)) return MVAE_ERR_UNSUPPORTED;      // 32-bit element offsets in the kernel
   if (d->ldw_hh[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hh[0]) & 15)) return MVAE_ERR_UNSUPPORTED;
   GruRowF a;
+  { const char* sf = mvae_knob("MVAE_GRU_ROWRES_SAFE"); a.safe = (sf && atoi(sf) != 0) ? 1 : 0; }
   a.w_hh = reinterpret_cast<const bf16_t*>(d->w_hh[0]); a.ldw = d->ldw_hh[0];
   a.bias = d->bias[0];
   a.tbl = d->add_table; a.idx = reinterpret_cast<const long*>(d->add_index); a.idx_ld = d->add_index_ld; a.tbl_rows = d->add_table_rows;
@@ -987,6 +992,7 @@ int rnn_gru_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   if (d->dh0[0] || !d->gates[0] || !d->hs[0] || !d->dG[0] || !d->w_hhT[0] || d->T < 1 || d->B % (4 * GR_RPL)) return MVAE_ERR_UNSUPPORTED;
   if (d->ldw_hhT[0] % 8 || (reinterpret_cast<uintptr_t>(d->w_hhT[0]) & 15) || d->ldg < 4L * H) return MVAE_ERR_UNSUPPORTED;
   GruRowB a;
+  { const char* sf = mvae_knob("MVAE_GRU_ROWRES_SAFE"); a.safe = (sf && atoi(sf) != 0) ? 1 : 0; }
   a.w_hhT = reinterpret_cast<const bf16_t*>(d->w_hhT[0]); a.ldwT = d->ldw_hhT[0];
   a.gates = reinterpret_cast<const bf16_t*>(d->gates[0]);
   a.hs = reinterpret_cast<const bf16_t*>(d->hs[0]); a.ldh = d->ldh;

@@ -60,9 +60,10 @@ def test_train_zinc_example_trains_checkpoints_and_reloads(tmp_path):
     mv.load_checkpoint(r["checkpoint"], model, opt)
     assert abs(opt.param_groups[0]["lr"] - ck["lr"]) < 1e-12
     val, acc = mv.evaluate(model, mv.make_loss_function(120), test_ds.batches(128, shuffle=False, drop_last=False))
-    # (the reparameterisation noise of models.py:92 is drawn afresh in every forward, here and in the child run: 1e-2-scaled, so the two
-    # evaluations agree to ~1e-5, not to the bit)
-    assert abs(val - ep[-1]["val_loss"]) < 1e-3 * abs(val) and abs(acc - ep[-1]["val_acc"]) < 0.02
+    # (the reparameterisation noise of models.py:92 is drawn afresh in every forward, here and in the child run: 1e-2-scaled.  How far two
+    # evaluations of the SAME weights differ depends on where training has taken the model: 1e-7 after two epochs, +-0.4 % after three
+    # (measured: 9.641 / 9.607 / 9.605 from three evaluate() calls in a row, tests/tuning/persist/dbg_e2e.py) -- the bound is 1 %)
+    assert abs(val - ep[-1]["val_loss"]) < 1e-2 * abs(val) and abs(acc - ep[-1]["val_acc"]) < 0.02
     # generation from latents (train_sample.py:29-45): decoder-only forward pass, arg-max, charset, rstrip
     g = torch.Generator(device="cuda").manual_seed(3)
     strings, z = mv.generate_from_latent(model, ck["charset"], n=96, batch_size=40, generator=g)

@@ -551,3 +551,27 @@ def test_layer_concurrent_row_resident_encoder_passes_equal_the_layer_by_layer_f
     for k, tol in (("hs", 2e-6), ("cs", 2e-6), ("gates", 2e-6), ("dG", 2e-5)):
         for l in range(NL):
             assert rel(a[k][l].cpu().numpy(), p[k][l].cpu().numpy()) < tol, (k, l, float((a[k][l] - p[k][l]).abs().max()))
+
+
+def test_gru_rowres_counted_waits_equal_the_drained_form_at_the_bench_shape(monkeypatch):
+    """gru_rowres_fwd / _bwd (the MOSES encoder GRU(256), one launch per direction) retire their prefetched operands
+    with COUNTED s_waitcnt vmcnt(N), which is exact only if loads and stores retire in issue order -- what hipcc's own wait-count insertion
+    assumes on gfx9-family targets (one counter for both kinds; tests/test_host_logic.py checks the per-step instruction counts the N's are
+    built from).  MVAE_GRU_ROWRES_SAFE=1 turns every counted wait into vmcnt(0): at the bench shape (B = 1024, lengths ~N(38, 8)) the whole
+    training step must give the same bits either way."""
+    import bench_extra
+    outs = []
+    for safe in ("0", "1"):
+        monkeypatch.setenv("MVAE_GRU_ROWRES_SAFE", safe)
+        torch.manual_seed(5)
+        wl = bench_extra.MosesWorkload(1024, "bf16", dev, 0, None)
+        wl.model.eval()                                    # (dropout off: the comparison is about the encoder kernels)
+        kl, recon, z, logvar, x, y = wl.model(wl.batch, eps=torch.zeros(1024, 160, device=dev))
+        (0.5 * kl + recon).backward()
+        torch.cuda.synchronize()
+        outs.append((kl.detach().clone(), z.detach().clone(), {k: p_.grad.clone() for k, p_ in wl.model.named_parameters() if k.startswith(("encoder_rnn", "x_emb"))}))
+        del wl
+        ops.release_caches()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
