@@ -320,9 +320,9 @@ def test_two_rank_sharded_optimizer_checkpoint_needs_gather_state(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------- weights-resident dataflow LSTM forward (b = 128)
-def _persist_case(T, seed=0):
+def _persist_case(T, seed=0, B=128):
     from molecular_vae_amd import _lib as L
-    B, H, NL, PAD = 128, 1024, 4, 64
+    H, NL, PAD = 1024, 4, 64
     G4, ldw, ldh = 4 * H, H + PAD, H + PAD
     g = torch.Generator(device="cuda").manual_seed(seed)
     rnd = lambda *s: (torch.randn(*s, device=dev, generator=g) * 0.03)
@@ -349,6 +349,18 @@ def _close_bf16(x, y, ulps=2.0):
 
 
 import math
+
+
+def test_persistent_dataflow_forward_serves_256_rows_as_two_passes():
+    """B = 256 (the per-rank batch of a 4-GPU job): two passes over 128 independent rows each, same buffers, same results as the wavefront."""
+    run, (T, B, H, NL) = _persist_case(9, seed=2, B=256)
+    n0 = ops.PERSIST_STATS["launches"]
+    a, p = run(False), run(True)
+    ops.persist_check(sync=True)
+    assert ops.PERSIST_STATS["launches"] == n0 + 1
+    for l in range(NL):
+        assert _close_bf16(a["hs"][l][:, :, :H], p["hs"][l][:, :, :H]) and _close_bf16(a["gates"][l], p["gates"][l]) and _close_bf16(a["cs"][l], p["cs"][l]), l
+        assert _close_bf16(a["cstate"][l][(T - 1) & 1], p["cstate"][l][(T - 1) & 1], ulps=4.0), l
 
 
 @pytest.mark.parametrize("T", [1, 2, 7, 120])
