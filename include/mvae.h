@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 7
+#define MVAE_ABI_VERSION 8
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -257,9 +257,18 @@ typedef struct {
    * (dG^{l+1}_t . W_ih^{l+1}) is multiplied by keep(l,t,b,j) / (1 - p).  drop_p == 0: no dropout. */
   const uint8_t* drop_mask[MVAE_MAX_LAYERS];
   float drop_p; uint32_t drop_seed;
+  /* Optional second schedule, the WEIGHTS-RESIDENT DATAFLOW backward (rnn_persist_bwd.hip), the counterpart of mvae_rnn_fwd_desc.persist_ws: ONE
+   * persistent launch of 256 workgroups, each keeping a (64 hidden units x one gate's K-quarter) slice of [W_hh^T | W_ih^T] in registers for
+   * all T steps; the dG tiles and the K-quarter partial sums travel between workgroups through write-through stores + flag words.  Serves
+   * LSTM, bf16, 4 layers, H = 1024, B = 128 (256: two passes), ldg = 4H + 64, the output gradient given as dy (fp32, dy_ld = H; not dy_a), no
+   * dh_last / dropout, on a 256-CU device with nothing else running beside it: mvae_rnn_bwd_persist_workspace() returns 0 for everything else.
+   * persist_ws != NULL (that many bytes, 16-byte aligned) selects it; its first 16 bytes are the status record (word 0 != 0: a bounded spin
+   * ran out, dG is invalid).  dstate is not written by this schedule (the carried dc never leaves the registers). */
+  void* persist_ws; size_t persist_ws_bytes;
 } mvae_rnn_bwd_desc;
 
 int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream);
+size_t mvae_rnn_bwd_persist_workspace(const mvae_rnn_bwd_desc* d);   /* 0: this shape / device is not served by the persistent schedule */
 /* bytes of split_ws that let mvae_rnn_bwd pick any of its schedules for this shape (reads layers, T, B, H only). */
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d);
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = ((os.environ.get("MVAE_LIB") if os.environ.get("MVAE_TUNING", "0") not in ("", "0") else None)
             or os.path.join(_HERE, "libmvae_hip.so"))      # MVAE_LIB too is honoured only under MVAE_TUNING=1
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MVAE_F32, MVAE_BF16, MVAE_F32X3 = 0, 1, 2
 CONV_BWD_X3 = 0x100
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
@@ -59,7 +59,8 @@ class RnnBwdDesc(C.Structure):
                 ("dstate", _vp * MAX_LAYERS),
                 ("dh0", _vp * MAX_LAYERS),
                 ("split_ws", _vp), ("split_ws_bytes", _sz),
-                ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32)]
+                ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32),
+                ("persist_ws", _vp), ("persist_ws_bytes", _sz)]
 
 
 class GemmTnProblem(C.Structure):
@@ -102,6 +103,7 @@ SIGNATURES = {
     "mvae_gemm_tn_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
     "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),
     "mvae_rnn_bwd_workspace": (_sz, [C.POINTER(RnnBwdDesc)]),
+    "mvae_rnn_bwd_persist_workspace": (_sz, [C.POINTER(RnnBwdDesc)]),
     "mvae_rowsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp]),
     "mvae_timesum": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "mvae_colsum_workspace": (_sz, [_i, _i]),

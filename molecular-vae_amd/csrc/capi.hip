@@ -85,7 +85,11 @@ size_t mvae_rnn_fwd_persist_workspace(const mvae_rnn_fwd_desc* d) {
   if (rnn_persist_fwd_supported(d)) return rnn_persist_fwd_workspace_bytes(d->T);
   return rnn_rowres_fwd_pipe_workspace(d);
 }
-int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) { return rnn_bwd_impl(d, (hipStream_t)stream); }
+int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) {
+  if (d && d->persist_ws && rnn_persist_bwd_supported(d)) return rnn_persist_bwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream);
+  return rnn_bwd_impl(d, (hipStream_t)stream);
+}
+size_t mvae_rnn_bwd_persist_workspace(const mvae_rnn_bwd_desc* d) { return (d && rnn_persist_bwd_supported(d)) ? rnn_persist_bwd_workspace_bytes(d->T) : 0; }
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d) { return rnn_bwd_workspace_bytes(d); }
 
 }  // extern "C"

@@ -32,4 +32,8 @@ int launch_selu_bwd(long n, float* dy, const float* y, hipStream_t st);
 bool rnn_persist_fwd_supported(const mvae_rnn_fwd_desc* d);
 size_t rnn_persist_fwd_workspace_bytes(int T);
 int rnn_persist_fwd(const mvae_rnn_fwd_desc* d, void* ws, size_t ws_bytes, hipStream_t st);
+// rnn_persist_bwd.hip: weights-resident dataflow LSTM backward (same shape)
+bool rnn_persist_bwd_supported(const mvae_rnn_bwd_desc* d);
+size_t rnn_persist_bwd_workspace_bytes(int T);
+int rnn_persist_bwd(const mvae_rnn_bwd_desc* d, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rnn_rowres_fwd_pipe_workspace(const mvae_rnn_fwd_desc* d);     // rnn_rowres.hip: layer-concurrent row-resident LSTM forward

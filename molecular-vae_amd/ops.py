@@ -509,7 +509,7 @@ def dropout_keep_mask(seed, shape_lt_b_h, p):
 # else held a CU): it then leaves a status record, which is copied to pinned host memory behind the launch and checked at the next call
 # and by persist_check().
 PERSIST_DEFAULT = "1"
-PERSIST_STATS = {"launches": 0, "rowres_pipe": 0}     # passes that took the persistent decoder schedule / the layer-concurrent encoder form (tests / logs)
+PERSIST_STATS = {"launches": 0, "rowres_pipe": 0, "bwd_launches": 0}     # passes that took the persistent decoder schedule / the layer-concurrent encoder form (tests / logs)
 _PERSIST_PENDING = []      # [(pinned int32[4], event, what)]
 
 
@@ -590,9 +590,11 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
 
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dstate,
             ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dh0=None, tag=None,
-            drop_mask=None, drop_p=0.0, drop_seed=0, dy_a=None, dy_w=None, dy_k=0):
+            drop_mask=None, drop_p=0.0, drop_seed=0, dy_a=None, dy_w=None, dy_k=0, persist=None):
     """dy_a [T*B, ld] / dy_w [H, ld] (dtype, zero-padded to dy_k columns): the output gradient as a product dy = dy_a . dy_w^T, contracted
-    by the top layer's cell itself (no [T, B, H] fp32 dy tensor)."""
+    by the top layer's cell itself (no [T, B, H] fp32 dy tensor).
+    persist: True / False / None (= PERSIST_DEFAULT): the weights-resident dataflow backward where the library serves the shape (it wants the
+    output gradient as `dy`, see rnn_bwd_persist_served)."""
     d = L.RnnBwdDesc()
     NL = len(w_hhT)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
@@ -627,8 +629,25 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     need = L.load().mvae_rnn_bwd_workspace(C.byref(d))     # scratch of the split-K schedules (used only when the shape qualifies)
     sws = Scratch.get(need, dy.device if dy is not None else dG[0].device, tag="rnn_split")
     d.split_ws, d.split_ws_bytes = sws.data_ptr(), need
+    use_p = (L.knob("MVAE_PERSIST_BWD", PERSIST_DEFAULT) != "0") if persist is None else bool(persist)
+    pws = None
+    if use_p:
+        pneed = L.load().mvae_rnn_bwd_persist_workspace(C.byref(d))
+        if pneed:
+            persist_check()
+            pws = Scratch.get(pneed, dG[0].device, tag="rnn_persist_bwd")
+            d.persist_ws, d.persist_ws_bytes = pws.data_ptr(), pneed
+        elif persist:
+            raise L.MvaeError("rnn_bwd(persist=True): this shape / device / gradient form is not served by the persistent schedule")
     with _Timed(tag):
         check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr()), "mvae_rnn_bwd")
+    if pws is not None:
+        PERSIST_STATS["bwd_launches"] += 1
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(pws[:16].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        _PERSIST_PENDING.append((host, ev, tag or "mvae_rnn_bwd"))
+        return
     if cell == L.CELL_LSTM and dtype == torch.float32 and H == 72 and 2 <= NL <= 3 and need:
         # the layer-concurrent row-resident backward (rnn_rowres.hip) polls progress words with BOUNDED spins; its status word sits behind
         # them in the workspace: [2 x T x B x H fp32 | NL x ceil(B / 4) words | status] -- checked like the persistent forward's

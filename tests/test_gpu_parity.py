@@ -28,7 +28,7 @@ def t(a, dt=torch.float32):
 
 def test_native_library_is_the_one_running():
     lib = L.load()
-    assert lib.mvae_abi_version() == L.ABI_VERSION == 7
+    assert lib.mvae_abi_version() == L.ABI_VERSION == 8
     assert os.path.samefile(L.LIB_PATH, os.path.join(ROOT, "molecular-vae_amd", "libmvae_hip.so"))
     assert any("libmvae_hip.so" in line for line in open("/proc/self/maps"))
 

@@ -26,14 +26,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mvae.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert lib.mvae_abi_version() == L.ABI_VERSION == 7
+    assert lib.mvae_abi_version() == L.ABI_VERSION == 8
     assert lib.mvae_status_string(-2) == b"workspace too small"
 
 
 def test_struct_layout_matches_header():
     # sizes computed by hand from include/mvae.h (LP64): guards the ctypes mirror against drift
     assert ctypes.sizeof(L.RnnFwdDesc) == 7 * 4 + 4 + 8 * 4 + (8 * 3 + 8) + 8 * (8 * 4) + 8 * 8 + 8 * 8 + 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + (8 * 8 * 2 + 8) + 16
-    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + (8 * 4 + 8) + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3 + 16 + (8 * 8 + 8)
+    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + (8 * 4 + 8) + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3 + 16 + (8 * 8 + 8) + 16
     # ... and against what the compiler laid out (the loader refuses a mismatch as well)
     lib = L.load()
     for which, st in enumerate((L.RnnFwdDesc, L.RnnBwdDesc, L.GemmTnProblem)):
