@@ -9,9 +9,13 @@
 //     quarter), and takes in only ITS quarter of the two dG blocks per step: 128 rows x 2 x 1024 k = 512 KB (the forward pass's intake), by
 //     LDS-DMA into per-wave rings, exactly the forward kernel's operand path (rnn_persist.hip);
 //   * the four K-slice partials of the waves are exchanged through LDS (as in the forward pass), which leaves the workgroup with its
-//     K-QUARTER partial of dh [128 x 64]; the four workgroups (blk, 0..3) exchange those through a 2-deep ring in global memory (write-through
-//     16-byte stores into slots that hold a sentinel until then: the payload is its own flag): workgroup kq receives the 16 units 64 blk + 16 kq .. + 15 from all four, sums them in the
-//     fixed order kq = 0, 1, 2, 3, and does the gate-derivative math for 128 rows x 16 units (dc carried in registers for the whole pass);
+//     K-QUARTER partial of dh [128 rows x 64 units]; the four workgroups (blk, 0..3) exchange those through a 2-deep ring in global memory:
+//     workgroup kq receives BATCH ROWS 32 kq .. + 31 of all 64 units from all four, sums them in the fixed order kq = 0, 1, 2, 3, and does
+//     the gate-derivative math for 32 rows x 64 units, one row x 8 consecutive units per lane (dc carried in registers for the whole pass):
+//     a row's 64 units are 128 contiguous bytes per gate, so every saved-state load and dG store moves whole memory lines (a 16-unit x
+//     128-row split would move 32-byte pieces: 3 x the issue time and 2.4 x the latency per instruction, tests/tuning/vmem).  The payload
+//     is its own flag: every fp32 word carries the phase of its ring slot's use in its lowest mantissa bit (one ulp of a K-quarter partial
+//     sum that is rounded to bf16 a moment later), so the producer neither drains nor raises anything and the consumer polls the data itself;
 //   * dG^l_t goes out write-through, drained, and the workgroup raises dflags[l][t][j]; consumers (the same layer's 64 workgroups for step
 //     t - 1, the layer below's 64 for step t -- every one of them reads ONE gate's columns of ALL units) poll the 64 words of (l, t).
 // Every dG element is written once per launch; the exchange ring slot of step t is rewritten at step t - 2, when every reader has long
@@ -30,7 +34,7 @@ constexpr int PWG = 256;
 constexpr int RS = 6, SLOT = 4096, RING = RS * SLOT;
 constexpr int SCR_OFF = 4 * RING, SCR_BYTES = 12 * 4096;
 constexpr int PLDS = SCR_OFF + SCR_BYTES;         // 144 KB
-constexpr size_t EXCH_BYTES = (size_t)PNL * 2 * 16 * 4 * 4 * 2 * 4096;      // [layer][parity of t][blk][dst kq][src kq][half][256 lanes] float4 = 16 MB
+constexpr size_t EXCH_BYTES = (size_t)PNL * 2 * 16 * 4 * 4 * 8192;      // [layer][parity of t][blk][dst kq][src kq][plane 2][row 32][8 unit groups] float4 = 16 MB
 
 struct PersistBwdArgs {
   int T;
@@ -41,7 +45,7 @@ struct PersistBwdArgs {
   const void* cs[PNL];             // [T][Btot][H] bf16
   void* dG[PNL];                   // [T][Btot][LDG] bf16 (out)
   float* exch;                     // EXCH_BYTES
-  uint32_t* dflags;                // [PNL][T][2][64]: rows 64 hf .. + 63 of the dG^l_t tile of workgroup j are in memory
+  uint32_t* dflags;                // [PNL][T][64]: the dG^l_t tile of workgroup j is in memory
   uint32_t* status;
   uint32_t spin_limit;
   int safe;
@@ -57,9 +61,31 @@ struct PersistBwdArgs {
 typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_t;
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
 
-__device__ __forceinline__ void unpack4(const u32x2_t v, float (&o)[4]) {
-  o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xffff0000u);
-  o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xffff0000u);
+// 16-byte write-through buffer store.  Observed on gfx950 (tests/tuning/persist/ab_persist_bwd.py, first row-split build): with the scalar
+// offset in an SGPR the compiler emits no wait state between a buffer_store_dwordx4 and a VALU instruction that overwrites its data
+// registers (the documented exemption for SGPR offsets), and dword 1 of the stored vector then carried the NEXT value written to that
+// register in lanes 12-15 of every 16.  So: the whole offset goes through the VGPR (literal soffset 0: the compiler's hazard rule applies)
+// and a few idle cycles follow the store.
+__device__ __forceinline__ void store_b128_wt(u32x4_t v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, 16);
+  asm volatile("s_nop 3" ::: "memory");
+}
+
+// Poll the 64 flag words at byte offset `off` of the [status | flags] block: one 256-byte sc1 load per round, addressed through a buffer
+// resource (an SGPR base + lane * 4: no 64-bit per-lane pointer to keep alive across the step).  Returns false on timeout / abort.
+__device__ __forceinline__ bool wait_flags_b(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t lane4, uint32_t limit) {
+  for (uint32_t it = 0; it < limit; ++it) {
+    const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(r, lane4, off, 16);
+    asm volatile("" ::: "memory");                 // re-issued every round
+    if (__builtin_amdgcn_ballot_w64(v != 0u) == ~0ull) return true;
+    if ((it & 63) == 63) {
+      const uint32_t st = __builtin_amdgcn_raw_buffer_load_b32(r, 0u, 0u, 16);
+      asm volatile("" ::: "memory");
+      if (__builtin_amdgcn_readfirstlane(st) != 0u) return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
 }
 
 // HAS_X: layers < top (second K-segment = the layer above's dG of the same step); the top layer adds dy instead.
@@ -87,13 +113,11 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
         wh[g][kb] = *reinterpret_cast<const uint4*>(wr + row * ldr + col);
       }
   }
-  // The MFMA / LDS-exchange lane (n, q) holds batch rows 16 (4 hf + wave) + n, units 4 q .. + 3 of a 16-unit tile.  The FINALISER re-maps: lane
-  // i takes row fr = i >> 2 and units 4 fq .. + 3, fq = i & 3 -- it simply reads exchange slot fr + 16 fq instead of its own, a transposition
-  // that costs nothing -- so that four consecutive lanes cover the 32 contiguous bytes a row has per gate: 16 memory lines per load / store
-  // instruction instead of 64 (saved gates, cell states, dG).
-  const int fr = lane >> 2, fq = lane & 3;
-  const int u0 = 64 * blk + 16 * kq + 4 * fq;
-  float dc_reg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // The MFMA / LDS-exchange lane (n, q) of wave w holds, per half hf, batch row 16 (4 hf + w) + n, units 16 g + 4 q .. + 3 of the four unit
+  // tiles g.  The FINALISER lane i of wave w' takes row 32 kq + 8 w' + (i >> 3), units 8 (i & 7) .. + 7 of the block's 64.
+  const int frow = 32 * kq + 8 * wave + (lane >> 3);
+  const int u0 = 64 * blk + 8 * (lane & 7);
+  float dc_reg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const uint32_t ring = smem_base + (uint32_t)wave * RING;
   const uint32_t dg_bytes = (uint32_t)((long)T * p.Btot * LDG * 2);
@@ -108,16 +132,26 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) frag_off[kb] = (uint32_t)(n * 256 + (((4 * kb + q) ^ n) << 4));
 
-  uint32_t* myflags = p.dflags + (long)layer * T * 128;            // [t][half][64]
-  const uint32_t* xflags = HAS_X ? p.dflags + (long)(layer + 1) * T * 128 : nullptr;
+  // [status 64 B | dflags [PNL][T][64]] as one buffer: flag word (l, t, j) at byte 64 + ((l T + t) 64 + j) 4
+  const __amdgpu_buffer_rsrc_t r_fl = __builtin_amdgcn_make_buffer_rsrc(p.status, 0, 64 + PNL * T * 256, 0x00020000);
+  const uint32_t lane4 = (uint32_t)(lane << 2);
+  const uint32_t myfl = 64u + (uint32_t)(layer * T) * 256u, xfl = 64u + (uint32_t)((layer + 1) * T) * 256u;
+  auto wait_my = [&](int tt) { return wait_flags_b(r_fl, myfl + (uint32_t)tt * 256u, lane4, p.spin_limit); };
+  auto wait_x = [&](int tt) { return wait_flags_b(r_fl, xfl + (uint32_t)tt * 256u, lane4, p.spin_limit); };
   bool ok = true;
 
-  // slot list of a step as in the forward kernel: per 64-row half, x slots (dG^{l+1}_t) then h slots (dG^l_{t+1}); slot = (row tile ni, K-half kh)
-  constexpr int NSLOT = HAS_X ? 32 : 16, HALF = NSLOT / 2;
+  // Slot list of a step; slot = (row tile ni = 0 .. 7, K-half kh), 4 KB.  ALL x slots (dG^{l+1}_t: the layer above is a diagonal ahead) come
+  // first, then the h slots (dG^l_{t+1}: the layer's own previous step, published a moment ago):
+  //     layers < top:  x(ni 0..7) | h(ni 0..3) -> half 0 complete | h(ni 4..7) -> half 1 complete          (32 slots)
+  //     top layer:                  h(ni 0..3) -> half 0 complete | h(ni 4..7) -> half 1 complete          (16 slots)
+  // so that 11 slots (2.3 us) of work that does not depend on the layer's own flags stand between a publish and the poll for the others'
+  // (the first h slot is requested AHEAD = 5 slots before it is consumed) -- the flags' way through memory (1.5 us) is covered.  The price:
+  // both halves' accumulators (128 registers) are live through the x phase.
+  constexpr int NSLOT = HAS_X ? 32 : 16, NX = HAS_X ? 16 : 0, E0 = NX + 7, E1 = NX + 15;       // E0 / E1: last slot of half 0 / half 1
   constexpr int NST = 4;                           // stores of one half's K-quarter partial (per lane)
   constexpr int AHEAD = RS - 1;
-  auto slot_is_x = [](int s) { return HAS_X && (s % 16) < 8; };
-  auto slot_ni = [](int s) { return HAS_X ? 4 * (s / 16) + (s % 8) / 2 : s / 2; };
+  auto slot_is_x = [](int s) { return s < NX; };
+  auto slot_ni = [](int s) { return (s % 16) / 2; };
   auto slot_kh = [](int s) { return s % 2; };
   const __amdgpu_buffer_rsrc_t rhs = __builtin_amdgcn_make_buffer_rsrc(p.dG[layer], 0, (int)dg_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(HAS_X ? p.dG[layer + 1] : p.dG[layer], 0, (int)dg_bytes, 0x00020000);
@@ -133,58 +167,71 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
   auto step_base = [&](int tt) -> uint32_t { return (uint32_t)((tt < 0 || tt >= T) ? 0 : tt) * (uint32_t)(p.Btot * LDG * 2); };
   const uint32_t scr = smem_base + SCR_OFF;
   const uint32_t scr_lane = scr + (uint32_t)(lane << 4);
-  auto write_partials = [&](f32x4 (&acc)[4][4], f32x4 (&own)[4]) {
+  auto write_partials = [&](f32x4 (&acc)[8][4], auto hc, f32x4 (&own)[4]) {       // hc: which half's four row tiles
+    constexpr int o = 4 * decltype(hc)::value;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       if (d == wave) continue;
       const uint32_t base = scr_lane + (uint32_t)((3 * d + ((wave - d) & 3) - 1) << 12);
-      asm volatile("ds_write_b128 %0, %1" ::"v"(base), "v"(acc[d][0]) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(base), "v"(acc[d][1]) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(base), "v"(acc[d][2]) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(base), "v"(acc[d][3]) : "memory");
+      asm volatile("ds_write_b128 %0, %1" ::"v"(base), "v"(acc[o + d][0]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(base), "v"(acc[o + d][1]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(base), "v"(acc[o + d][2]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(base), "v"(acc[o + d][3]) : "memory");
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) own[g] = wave == 0 ? acc[0][g] : wave == 1 ? acc[1][g] : wave == 2 ? acc[2][g] : acc[3][g];
+    for (int g = 0; g < 4; ++g) own[g] = wave == 0 ? acc[o][g] : wave == 1 ? acc[o + 1][g] : wave == 2 ? acc[o + 2][g] : acc[o + 3][g];
   };
   // sum of the four waves' K-slice partials in the order of the SOURCE wave (row-position independent, see rnn_persist.hip)
   auto reduce_half = [&](f32x4 (&tot)[4]) {
     const uint32_t rbase = scr_lane + (uint32_t)((wave * 3) << 12);
-    f32x4 v[3][4];
-    v[0][0] = lds_rd<0>(rbase); v[0][1] = lds_rd<1024>(rbase); v[0][2] = lds_rd<2048>(rbase); v[0][3] = lds_rd<3072>(rbase);
-    v[1][0] = lds_rd<4096>(rbase); v[1][1] = lds_rd<5120>(rbase); v[1][2] = lds_rd<6144>(rbase); v[1][3] = lds_rd<7168>(rbase);
-    v[2][0] = lds_rd<8192>(rbase); v[2][1] = lds_rd<9216>(rbase); v[2][2] = lds_rd<10240>(rbase); v[2][3] = lds_rd<11264>(rbase);
-    wait_lgkmcnt<0>();
+    // two unit tiles at a time (24 registers of addends instead of 48: both halves' accumulators are live here)
+    auto two = [&](auto gc) {
+      constexpr int g0 = decltype(gc)::value;
+      f32x4 v[3][2];
+      v[0][0] = lds_rd<1024 * g0>(rbase); v[0][1] = lds_rd<1024 * g0 + 1024>(rbase);
+      v[1][0] = lds_rd<4096 + 1024 * g0>(rbase); v[1][1] = lds_rd<4096 + 1024 * g0 + 1024>(rbase);
+      v[2][0] = lds_rd<8192 + 1024 * g0>(rbase); v[2][1] = lds_rd<8192 + 1024 * g0 + 1024>(rbase);
+      wait_lgkmcnt<0>();
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 o = tot[g];
-      if (wave == 0) tot[g] = ((o + v[0][g]) + v[1][g]) + v[2][g];
-      else if (wave == 1) tot[g] = ((v[2][g] + o) + v[0][g]) + v[1][g];
-      else if (wave == 2) tot[g] = ((v[1][g] + v[2][g]) + o) + v[0][g];
-      else tot[g] = ((v[0][g] + v[1][g]) + v[2][g]) + o;
-    }
+      for (int k = 0; k < 2; ++k) {
+        const f32x4 o = tot[g0 + k];
+        if (wave == 0) tot[g0 + k] = ((o + v[0][k]) + v[1][k]) + v[2][k];
+        else if (wave == 1) tot[g0 + k] = ((v[2][k] + o) + v[0][k]) + v[1][k];
+        else if (wave == 2) tot[g0 + k] = ((v[1][k] + v[2][k]) + o) + v[0][k];
+        else tot[g0 + k] = ((v[0][k] + v[1][k]) + v[2][k]) + o;
+      }
+    };
+    two(std::integral_constant<int, 0>{});
+    two(std::integral_constant<int, 2>{});
   };
   // K-quarter partial of one half -> the exchange ring: m-tile g goes to workgroup (blk, g) (the own tile too: every reader finds four
   // addends in one place and sums them in the same order, whoever it is)
+  // Exchange ring: per (layer, parity of t, blk, dst, src) two planes of [32 rows][8 unit groups] float4: plane pl holds units 8 u8 + 4 pl .. + 3,
+  // so that a finaliser lane's two loads are each 1 KB contiguous per wave.  The writer's pieces (unit group 2 g + (q >> 1), plane q & 1)
+  // land scattered -- 16-byte stores, the cheaper side to scatter.
   const __amdgpu_buffer_rsrc_t r_ex = __builtin_amdgcn_make_buffer_rsrc(p.exch, 0, (int)EXCH_BYTES, 0x00020000);
-  const uint32_t ex_lane = (uint32_t)(tid << 4);
-  auto ex_off = [&](int par, int dst, int src, int hf) -> uint32_t {
-    return (uint32_t)(((((((layer * 2 + par) * 16 + blk) * 4 + dst) * 4 + src) * 2 + hf)) << 12);
-  };
+  auto ex_off = [&](int par, int dst, int src) -> uint32_t { return (uint32_t)((((((layer * 2 + par) * 16 + blk) * 4 + dst) * 4 + src)) << 13); };
+  const uint32_t ex_wr = (uint32_t)((q & 1) * 4096 + (16 * (wave & 1) + n) * 128 + (q >> 1) * 16);      // + 32 g
+  const uint32_t ex_rd = (uint32_t)(tid << 4);                                                          // + 4096 plane
+  // half hf of wave w goes to workgroup dst = 2 hf + (w >> 1) (its rows 16 (w & 1) .. + 15)
   auto send_half = [&](int t, int hf, const f32x4 (&tot)[4]) {
+    const uint32_t ph = (uint32_t)(((T - 1 - t) >> 1) & 1);
+    const uint32_t so = ex_off(t & 1, 2 * hf + (wave >> 1), kq);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, tot[g]), r_ex, ex_lane, ex_off(t & 1, g, kq, hf), 16);
+    for (int g = 0; g < 4; ++g) {
+      u32x4_t v = __builtin_bit_cast(u32x4_t, tot[g]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] & ~1u) | ph;
+      store_b128_wt(v, r_ex, ex_wr, so + (uint32_t)(32 * g));
+    }
     if (p.safe) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   const __amdgpu_buffer_rsrc_t r_gates = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gates[layer]), 0, (int)((long)T * p.Btot * 4 * PH * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_cs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.cs[layer]), 0, (int)((long)T * p.Btot * PH * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_X ? reinterpret_cast<const float*>(p.cs[layer]) : p.dy), 0,
                                                                        (int)((long)T * p.Btot * PH * (HAS_X ? 2 : 4)), 0x00020000);
-  const uint32_t row0 = rowoff + (uint32_t)(16 * wave + fr);
-  const uint32_t ex_rd = (uint32_t)((64 * wave + fr + 16 * fq) << 4);      // the exchange slot this lane finalises
-  const uint32_t voff_dg = (row0 * LDG + u0) * 2, voff_g = (row0 * 4 * PH + u0) * 2, voff_c = (row0 * PH + u0) * 2, voff_dy = (row0 * PH + u0) * 4;
 
-  if (HAS_X) ok = wait_flags(xflags + (long)(T - 1) * 128, p.status, p.spin_limit, lane);
+  if (HAS_X) ok = wait_x(T - 1);
   if (HAS_X) {
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) {
@@ -197,7 +244,7 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
   for (int t = T - 1; t >= 0 && ok; --t) {
     PBWD_STAMP(0);
     if (!HAS_X) {
-      if (t < T - 1) ok = ok && wait_flags(myflags + (long)(t + 1) * 128, p.status, p.spin_limit, lane);
+      if (t < T - 1) ok = ok && wait_my(t + 1);
       PBWD_STAMP(2);
       ipos = cpos;
 #pragma unroll
@@ -209,36 +256,34 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
     }
     const uint32_t xb = step_base(t), hb = step_base(t + 1), xb_next = step_base(t - 1);
     const uint32_t hmask = (t < T - 1) ? 0xffffffffu : 0u;
-    f32x4 acc[4][4], own0[4], own1[4];
+    f32x4 acc[8][4], own0[4], own1[4];
+    // saved forward state of this lane's 8 cells: cold HBM reads, whole lines.  Requested in front of half 1's LDS exchange, where nothing
+    // waits on the memory queue for the next ~2 us (the exchange, the partial stores, the partner workgroups' partials on their way).
+    u32x4_t sg[4], sc_, scp, sdy[2];
     auto slot_body = [&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      if constexpr (s % HALF == 0) {
+      if constexpr (s == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      // Flags are per 64-row HALF (the two halves of the batch are independent recurrences that take turns on this CU: while one half's
-      // hand-off is on its way, the other half's slots are streamed).  The slot issued in THIS iteration (s + AHEAD) needs:
-      if constexpr (HAS_X && s + AHEAD == 8) {                    // first h slot of half 0: the layer's own step t + 1, half 0
+      // flags the slot issued in THIS iteration (s + AHEAD) needs
+      if constexpr (HAS_X && s + AHEAD == NX) {                   // the first h slot: the layer's own step t + 1
         if (t < T - 1) {
           PBWD_STAMP(1);
-          ok = ok && wait_flags(myflags + (long)(t + 1) * 128, p.status, p.spin_limit, lane);
+          ok = ok && wait_my(t + 1);
           PBWD_STAMP(2);
         }
       }
-      if constexpr (HAS_X && s + AHEAD == 16) ok = ok && wait_flags(xflags + (long)t * 128 + 64, p.status, p.spin_limit, lane);      // first x slot of half 1
-      if constexpr (s + AHEAD == (HAS_X ? 24 : 8)) {              // first h slot of half 1
-        if (t < T - 1) ok = ok && wait_flags(myflags + (long)(t + 1) * 128 + 64, p.status, p.spin_limit, lane);
-      }
-      if constexpr (HAS_X && s + AHEAD == NSLOT) {                // the next step's first x slot (half 0)
-        if (t > 0) ok = ok && wait_flags(xflags + (long)(t - 1) * 128, p.status, p.spin_limit, lane);
+      if constexpr (HAS_X && s + AHEAD == NSLOT) {                // the next step's first x slot: the layer above's step t - 1
+        if (t > 0) ok = ok && wait_x(t - 1);
       }
       constexpr int younger = (HAS_X ? (AHEAD - 1) : ((NSLOT - 1 - s) < (AHEAD - 1) ? (NSLOT - 1 - s) : (AHEAD - 1))) * 4;
-      constexpr int stores_behind = (s > HALF - 1 && s <= HALF - 1 + AHEAD) ? NST : 0;
+      constexpr int stores_behind = (s > E0 && s <= E0 + AHEAD) ? NST : 0;
       wait_vmcnt<younger + stores_behind>();
-      constexpr bool isx = HAS_X && (s % 16) < 8;
-      constexpr int ti = (HAS_X ? (s % 8) / 2 : (s / 2) % 4), kh = s % 2;
+      constexpr bool isx = s < NX;
+      constexpr int ti = (s % 16) / 2, kh = s % 2;
       const uint32_t sb = ring + cpos;
       u32x4 b[4];
 #pragma unroll
@@ -254,24 +299,40 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
           acc[ti][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, b[kb]), acc[ti][g], 0, 0, 0);
         }
         if constexpr (refill) {
-          if constexpr (s + AHEAD < NSLOT) issue1(s + AHEAD, ((s + AHEAD) % 16 < 8 && HAS_X) ? xb : hb, kb);
+          if constexpr (s + AHEAD < NSLOT) issue1(s + AHEAD, (s + AHEAD < NX) ? xb : hb, kb);
           else issue1(s + AHEAD - NSLOT, xb_next, kb);
         }
       }
       advance(cpos);
       if constexpr (refill) advance(ipos);
-      if constexpr (s == HALF - 1) {
+      if constexpr (s == E0) {
         PBWD_STAMP(3);
-        write_partials(acc, own0);
+        write_partials(acc, std::integral_constant<int, 0>{}, own0);
         wait_lgkmcnt<0>();
         raw_barrier();
         reduce_half(own0);
         send_half(t, 0, own0);
       }
-      if constexpr (s == NSLOT - 1) {
+      if constexpr (s == E1) {
         PBWD_STAMP(4);
         raw_barrier();
-        write_partials(acc, own1);
+        write_partials(acc, std::integral_constant<int, 1>{}, own1);
+        {
+          // (lane offsets derived here, from one opaque copy of the lane's row: kept alive across the step they would cost four registers)
+          uint32_t row0 = rowoff + (uint32_t)frow;
+          asm volatile("" : "+v"(row0));
+          const uint32_t voff_g = (row0 * 4 * PH + u0) * 2, voff_c = (row0 * PH + u0) * 2, voff_dy = (row0 * PH + u0) * 4;
+          const uint32_t hrow = (uint32_t)(t * p.Btot);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) sg[g] = __builtin_amdgcn_raw_buffer_load_b128(r_gates, voff_g, hrow * (uint32_t)(4 * PH * 2) + (uint32_t)(g * PH * 2), 0);
+          sc_ = __builtin_amdgcn_raw_buffer_load_b128(r_cs, voff_c, hrow * (uint32_t)(PH * 2), 0);
+          const uint32_t prow = (uint32_t)((t > 0 ? t - 1 : 0) * p.Btot);
+          scp = __builtin_amdgcn_raw_buffer_load_b128(r_cs, voff_c, prow * (uint32_t)(PH * 2), 0);
+          if (!HAS_X) {
+            sdy[0] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, voff_dy, hrow * (uint32_t)(PH * 4), 0);
+            sdy[1] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, voff_dy, hrow * (uint32_t)(PH * 4) + 16u, 0);
+          }
+        }
         wait_lgkmcnt<0>();
         raw_barrier();
         reduce_half(own1);
@@ -280,101 +341,87 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
     };
     for_each_slot(slot_body, std::make_integer_sequence<int, NSLOT>{});
     PBWD_STAMP(5);
-    // ---- saved forward state of this lane's cells (both halves), requested behind the last partial stores
-    u32x2_t sg[2][4], sc_[2], scp[2];
-    u32x4_t sdy[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const uint32_t hrow = (uint32_t)(t * p.Btot + 64 * hf);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) sg[hf][g] = __builtin_amdgcn_raw_buffer_load_b64(r_gates, voff_g, hrow * (uint32_t)(4 * PH * 2) + (uint32_t)(g * PH * 2), 0);
-      sc_[hf] = __builtin_amdgcn_raw_buffer_load_b64(r_cs, voff_c, hrow * (uint32_t)(PH * 2), 0);
-      const uint32_t prow = (uint32_t)((t > 0 ? t - 1 : 0) * p.Btot + 64 * hf);
-      scp[hf] = __builtin_amdgcn_raw_buffer_load_b64(r_cs, voff_c, prow * (uint32_t)(PH * 2), 0);
-      if (!HAS_X) sdy[hf] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, voff_dy, hrow * (uint32_t)(PH * 4), 0);
-    }
-    // ---- the four K-quarter partials of this workgroup's 16 units: every exchange slot holds the SENTINEL (all ones: a NaN no arithmetic
-    // produces) until its producer's 16-byte store lands, so the data is its own flag -- the producer neither drains nor raises anything, the
-    // consumer polls the payload itself -- and the consumer puts the sentinel back once it has the values (the slot's next store comes two
-    // steps later, behind two rounds of dG flags that this workgroup raises after draining the re-arming stores).
-    const float cpm = t > 0 ? 1.f : 0.f;
-    auto recv_half = [&](int hf, u32x4_t (&part)[4]) -> bool {
+    // ---- the four K-quarter partials of this workgroup's 32 rows: polled until every word carries this use's phase bit
+    u32x4_t part[4][2];
+    {
+      const uint32_t ph = (uint32_t)(((T - 1 - t) >> 1) & 1);
       bool got = false;
       for (uint32_t it = 0; it < p.spin_limit && !got; ++it) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) part[s] = __builtin_amdgcn_raw_buffer_load_b128(r_ex, ex_rd, ex_off(t & 1, kq, s, hf), 16);
-        bool missing = false;
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) part[s][pl] = __builtin_amdgcn_raw_buffer_load_b128(r_ex, ex_rd, ex_off(t & 1, kq, s) + (uint32_t)(4096 * pl), 16);
+        uint32_t all1 = 1u, any1 = 0u;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) missing = missing || (part[s][e] == 0xffffffffu);
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { all1 &= part[s][pl][e]; any1 |= part[s][pl][e]; }
+        const bool missing = ph ? ((all1 & 1u) == 0u) : ((any1 & 1u) != 0u);
         asm volatile("" ::: "memory");              // the loads are re-issued every round
         got = __builtin_amdgcn_ballot_w64(missing) == 0ull;
         if (!got) {
           if ((it & 63) == 63) {
-            uint32_t sv;
-            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(sv) : "v"(p.status) : "memory");
+            const uint32_t sv = __builtin_amdgcn_raw_buffer_load_b32(r_fl, 0u, 0u, 16);
+            asm volatile("" ::: "memory");
             if (__builtin_amdgcn_readfirstlane(sv) != 0u) break;
           }
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      return got;
-    };
-    // re-arm the four slots, gate-derivative math of one half, dG stores (write-through): 8 stores per lane
-    auto finish_half = [&](int hf, const u32x4_t (&part)[4]) {
-      const u32x4_t ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      ok = ok && got;
+    }
+    PBWD_STAMP(6);
+    if (!ok) break;
+    {
+      const float cpm = t > 0 ? 1.f : 0.f;
+      float dh[8], gi[8], gf[8], gg[8], go[8], c[8], cp[8], di[8], df[8], dg[8], dO[8];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) __builtin_amdgcn_raw_buffer_store_b128(ones, r_ex, ex_rd, ex_off(t & 1, kq, s, hf), 16);
-      const f32x4 dhv = ((__builtin_bit_cast(f32x4, part[0]) + __builtin_bit_cast(f32x4, part[1])) + __builtin_bit_cast(f32x4, part[2])) + __builtin_bit_cast(f32x4, part[3]);
-      float gi[4], gf[4], gg[4], go[4], c[4], cp[4], di[4], df[4], dg[4], dO[4];
-      unpack4(sg[hf][0], gi); unpack4(sg[hf][1], gf); unpack4(sg[hf][2], gg); unpack4(sg[hf][3], go);
-      unpack4(sc_[hf], c); unpack4(scp[hf], cp);
+      for (int pl = 0; pl < 2; ++pl) {
+        const f32x4 v = ((__builtin_bit_cast(f32x4, part[0][pl]) + __builtin_bit_cast(f32x4, part[1][pl])) + __builtin_bit_cast(f32x4, part[2][pl])) +
+                        __builtin_bit_cast(f32x4, part[3][pl]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float dh = dhv[e];
-        if (!HAS_X) dh += __uint_as_float(sdy[hf][e]);
+        for (int e = 0; e < 4; ++e) dh[4 * pl + e] = v[e];
+      }
+      auto unpack8 = [](const u32x4_t v, float (&o)[8]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(v[k] << 16); o[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u); }
+      };
+      unpack8(sg[0], gi); unpack8(sg[1], gf); unpack8(sg[2], gg); unpack8(sg[3], go); unpack8(sc_, c); unpack8(scp, cp);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = dh[e];
+        if (!HAS_X) d += __uint_as_float(sdy[e >> 2][e & 3]);
         const float tc = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * c[e])), 1.f);
-        const float d_o = dh * tc;
-        const float dc = dh * go[e] * (1.f - tc * tc) + dc_reg[hf][e];
-        dc_reg[hf][e] = dc * gf[e];
+        const float d_o = d * tc;
+        const float dc = d * go[e] * (1.f - tc * tc) + dc_reg[e];
+        dc_reg[e] = dc * gf[e];
         di[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
         df[e] = dc * (cp[e] * cpm) * gf[e] * (1.f - gf[e]);
         dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
         dO[e] = d_o * go[e] * (1.f - go[e]);
       }
-      auto pack4 = [](const float (&v)[4]) -> u32x2_t {
-        u32x2_t r = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+      auto pack8 = [](const float (&v)[8]) -> u32x4_t {
+        u32x4_t r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
         return r;
       };
-      const uint32_t so = (uint32_t)(t * p.Btot + 64 * hf) * (uint32_t)(LDG * 2);
-      __builtin_amdgcn_raw_buffer_store_b64(pack4(di), rhs, voff_dg, so, 16);
-      __builtin_amdgcn_raw_buffer_store_b64(pack4(df), rhs, voff_dg, so + (uint32_t)(PH * 2), 16);
-      __builtin_amdgcn_raw_buffer_store_b64(pack4(dg), rhs, voff_dg, so + (uint32_t)(2 * PH * 2), 16);
-      __builtin_amdgcn_raw_buffer_store_b64(pack4(dO), rhs, voff_dg, so + (uint32_t)(3 * PH * 2), 16);
-      if (p.safe) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto raise = [&](int hf) {
-      raw_barrier();
-      if (tid == 0) {
-        uint32_t one = 1u;
-        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(myflags + (long)t * 128 + hf * 64 + j), "v"(one) : "memory");
-      }
-    };
-    u32x4_t part0[4], part1[4];
-    ok = ok && recv_half(0, part0);
-    PBWD_STAMP(6);
-    if (!ok) break;
-    finish_half(0, part0);
-    // Half 1's partials are polled BEHIND half 0's stores in the memory queue (everything returns in issue order): once they are here, half
-    // 0's dG tile is in memory -- its flag goes up without a drain of its own.
-    ok = ok && recv_half(1, part1);
-    if (!ok) break;
-    raise(0);
-    finish_half(1, part1);
+      uint32_t row0 = rowoff + (uint32_t)frow;
+      asm volatile("" : "+v"(row0));
+      const uint32_t voff_dg = (row0 * LDG + u0) * 2;
+      const uint32_t so = (uint32_t)(t * p.Btot) * (uint32_t)(LDG * 2);
+      store_b128_wt(pack8(di), rhs, voff_dg, so);
+      store_b128_wt(pack8(df), rhs, voff_dg, so + (uint32_t)(PH * 2));
+      store_b128_wt(pack8(dg), rhs, voff_dg, so + (uint32_t)(2 * PH * 2));
+      store_b128_wt(pack8(dO), rhs, voff_dg, so + (uint32_t)(3 * PH * 2));
+    }
     PBWD_STAMP(7);
+    // ---- publish dG^l_t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    raise(1);
+    raw_barrier();
+    if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(1u, r_fl, 0u, myfl + (uint32_t)(t * 256 + j * 4), 16);
   }
   if (!ok) {
     if (lane == 0) {
@@ -394,9 +441,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(PersistBwdArgs
 
 }  // namespace
 
-// workspace: [status 64 B | dflags PNL x T x 2 x 64 words | exchange ring 16 MB, all ones at launch]
+// workspace: [status 64 B | dflags PNL x T x 64 words | exchange ring 16 MB, all ones at launch: phase bit 1, the first use of every slot writes phase 0]
 size_t rnn_persist_bwd_workspace_bytes(int T) {
-  size_t n = 64 + (size_t)PNL * T * 128 * 4;
+  size_t n = 64 + (size_t)PNL * T * 64 * 4;
   n = (n + 4095) & ~(size_t)4095;
   n += EXCH_BYTES;
 #ifdef MVAE_TUNING
@@ -429,7 +476,7 @@ int rnn_persist_bwd(const mvae_rnn_bwd_desc* d, void* ws, size_t ws_bytes, hipSt
     a.gates[l] = d->gates[l]; a.cs[l] = d->cs[l]; a.dG[l] = d->dG[l];
   }
   a.dy = d->dy;
-  const size_t flag_bytes = (size_t)PNL * d->T * 128 * 4;
+  const size_t flag_bytes = (size_t)PNL * d->T * 64 * 4;
   size_t head = 64 + flag_bytes;
   head = (head + 4095) & ~(size_t)4095;
   char* w = reinterpret_cast<char*>(ws);
@@ -453,7 +500,7 @@ int rnn_persist_bwd(const mvae_rnn_bwd_desc* d, void* ws, size_t ws_bytes, hipSt
     a.row0 = r0;
     if (r0 == 0) MVAE_CHECK_HIP(hipMemsetAsync(ws, 0, head, st));
     else MVAE_CHECK_HIP(hipMemsetAsync(w + 64, 0, flag_bytes, st));
-    MVAE_CHECK_HIP(hipMemsetAsync(w + head, 0xff, EXCH_BYTES, st));       // every exchange slot armed
+    MVAE_CHECK_HIP(hipMemsetAsync(w + head, 0xff, EXCH_BYTES, st));       // no word carries phase 0 yet
     hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(PWG), dim3(256), PLDS, st, a);
   }
   MVAE_CHECK_HIP(hipGetLastError());

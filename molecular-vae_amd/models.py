@@ -743,8 +743,12 @@ class _DecoderFn(torch.autograd.Function):
         gates = [W(f"gates{l}", (Lq, B, G4), dt) for l in range(NL)]
         # K8 backward
         # bf16 (and a hidden size the LDS-direct loop serves): the top LSTM cell contracts dl . W_out itself (no [T, B, H] fp32 dy tensor)
-        fuse_dy = dt == torch.bfloat16 and (4 * H) % 64 == 0
-        ldl = _dyk(Cv) if fuse_dy else Cp           # pad columns are allocated zero and never written
+        # The weights-resident dataflow backward (rnn_persist_bwd.hip: the per-rank shape of the 8-GPU configuration) wants dy as a tensor: one
+        # [T*B, H] GEMM in front of it instead of the fused segment.
+        fuse_ok = dt == torch.bfloat16 and (4 * H) % 64 == 0
+        use_pb = fuse_ok and ops.rnn_bwd_persist_wanted(L.CELL_LSTM, dt, NL, B, H, ldg, dev)
+        fuse_dy = fuse_ok and not use_pb
+        ldl = _dyk(Cv) if fuse_ok else Cp           # pad columns are allocated zero and never written
         dl = W("dl", (TB + 8, ldl), dt)[:TB]        # +8 rows: the TN tile reads 256-byte row segments past the last row
         dlT = None
         if dt != torch.bfloat16:
@@ -755,7 +759,7 @@ class _DecoderFn(torch.autograd.Function):
         dy = None
         if not fuse_dy:
             dy = W("dy", (TB, H))
-            ops.gemm_nt(dl, P["WoutT"], dy, TB, H, Cp)
+            ops.gemm_nt(dl, P["WoutT"], dy, TB, H, ldl if fuse_ok else Cp)
         # K7 backward
         dG = [W(f"dG{l}", (Lq, B, ldg), dt) for l in range(NL)]
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]

@@ -588,6 +588,17 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
         _PERSIST_PENDING.append((host, ev, tag or "mvae_rnn_fwd"))
 
 
+def rnn_bwd_persist_wanted(cell, dtype, NL, B, H, ldg, device):
+    """Would rnn_bwd take the weights-resident dataflow schedule for this shape if it is given the output gradient as `dy`?  (The library has
+    the last word -- mvae_rnn_bwd_persist_workspace -- this only lets the caller choose the gradient's form; a wrong guess costs speed, not
+    correctness.)"""
+    if L.knob("MVAE_PERSIST_BWD", PERSIST_DEFAULT) == "0":
+        return False
+    if cell != L.CELL_LSTM or dtype != torch.bfloat16 or NL != 4 or H != 1024 or B not in (128, 256) or ldg != 4 * H + 64:
+        return False
+    return torch.cuda.get_device_properties(device).multi_processor_count == 256
+
+
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dstate,
             ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dh0=None, tag=None,
             drop_mask=None, drop_p=0.0, drop_seed=0, dy_a=None, dy_w=None, dy_k=0, persist=None):

@@ -76,8 +76,19 @@ for l in range(NL):
     worst = max(worst, rel)
     bad = ((x - y).abs() > 0.02 * x.abs().max()).nonzero()
     print(f"dG[{l}] max |wavefront - dataflow| = {d:.3e}  (max |value| {x.abs().max().item():.3e}, rel {rel:.2e}, equal bits: {bool(torch.equal(x, y))}, finite: {bool(torch.isfinite(y).all())})")
-    if len(bad):
+    if len(bad) or not torch.isfinite(y).all():
+        worst = float("inf")
+        bad = (~((x - y).abs() <= 0.02 * x.abs().max())).nonzero()
         print("   first mismatches (t, row, col):", bad[:6].tolist(), " count", len(bad))
+        if os.environ.get("PB_DIAG"):
+            tt, rr, cc = bad[:, 0], bad[:, 1], bad[:, 2]
+            print("   by t:", torch.bincount(tt, minlength=T).tolist())
+            print("   by row // 8:", torch.bincount(rr // 8, minlength=B // 8).tolist())
+            print("   by gate:", torch.bincount(cc // H, minlength=4).tolist())
+            print("   by unit % 8:", torch.bincount(cc % 8, minlength=8).tolist())
+            print("   by (unit // 8) % 8:", torch.bincount((cc % H // 8) % 8, minlength=8).tolist())
+            print("   by unit block of 64:", torch.bincount(cc % H // 64, minlength=16).tolist())
+            print("   nan count:", int(torch.isnan(y).sum()))
 nl = T + NL - 1
 for label, persist in (("wavefront (2 x (T+3) launches)", False), ("dataflow  (one launch)        ", True)):
     ms = timeit(lambda: bwd(a if not persist else p, persist), REPS)
@@ -87,10 +98,10 @@ print("RESULT", "OK" if worst <= 1e-2 else "MISMATCH", f"(largest difference {wo
 if os.environ.get("MVAE_LIB"):
     from molecular_vae_amd.ops import Scratch
     ws = Scratch.get(1, dev, tag="rnn_persist_bwd")
-    head = (64 + NL * T * 128 * 4 + 4095) // 4096 * 4096
+    head = (64 + NL * T * 64 * 4 + 4095) // 4096 * 4096
     off = head + 16 * 1024 * 1024
     st = ws[off:off + NL * T * 64 * 64].view(torch.int64).view(NL, T, 64, 8).cpu().double() * 0.01      # us
-    names = ["start", "hflag poll", "hflag ok", "half0 slots done", "half1 slots done", "half1 partial sent", "half0 partials here", "half1 dG stored"]
+    names = ["start", "hflag poll", "hflag ok", "half0 slots done", "half1 slots done", "half1 partial sent", "partials received", "dG stored"]
     for l in range(NL):
         d = st[l].flip(0)          # [step in execution order][workgroup][stamp]
         per = (d[3:, :, 0] - d[2:-1, :, 0]).mean().item()
@@ -103,3 +114,24 @@ if os.environ.get("MVAE_LIB"):
             print(f"    {names[k]:22s} {x.mean().item():7.2f} {x.min().item():7.2f} {x.max().item():7.2f}   slowest wg j={int(x.argmax())} fastest j={int(x.argmin())}")
         busy = ((d[2:, :, 4] - d[2:, :, 2]).mean(dim=0))
         print("    streaming (hflag ok -> half1 slots done) per workgroup: " + " ".join(f"{v:.1f}" for v in busy.tolist()))
+if os.environ.get("PB_DUMP"):
+    l = NL - 1
+    x, y = a["dG"][l].float()[T - 1, :, :G4], p["dG"][l].float()[T - 1, :, :G4]
+    okm = ((x - y).abs() <= 0.02 * x.abs().max())
+    print("top layer, t = T-1: rows x (gate 0, units 0..23) ok-map (1 = ok)")
+    for r in range(0, 40):
+        print(f"  row {r:3d}: " + "".join("1" if okm[r, u] else "." for u in range(24)) + "   gate1: " + "".join("1" if okm[r, H + u] else "." for u in range(24)))
+    r, u = 1, 0
+    print("expected", x[1, :8].tolist()); print("got     ", y[1, :8].tolist())
+    # does the value sit somewhere else?
+    v = x[1, 0].item()
+    hit = ((y - v).abs() < 1e-7 * max(1.0, abs(v))).nonzero()
+    print("expected value of (row 1, unit 0) found at", hit[:8].tolist())
+if os.environ.get("PB_DUMP"):
+    bad = (~okm).nonzero()
+    print("top layer wrong entries:", len(bad), " by gate", torch.bincount(bad[:, 1] // H, minlength=4).tolist(), " nan", int(torch.isnan(y).sum()))
+    print("  by row % 32:", torch.bincount(bad[:, 0] % 32, minlength=32).tolist())
+    print("  by unit % 64:", torch.bincount(bad[:, 1] % 64, minlength=64).tolist())
+    for k in range(0, min(len(bad), 400), 40):
+        r_, c_ = int(bad[k, 0]), int(bad[k, 1])
+        print(f"   (row {r_}, gate {c_ // H}, unit {c_ % H}): expected {x[r_, c_].item():.6e} got {y[r_, c_].item():.6e}")
