@@ -216,11 +216,13 @@ class MolVaeWorkload:
         peak = BF16_DENSE_PEAK_TFLOPS if dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
         fused_bwd = dtype == "bf16" and self.B >= 1024 and self.B % 128 == 0
         from molecular_vae_amd import ops as _ops
-        persist = dtype == "bf16" and self.B == 128 and (self.L, H_DEC) == (self.L, 1024) and _ops.PERSIST_STATS["launches"] > 0
+        persist = dtype == "bf16" and self.B in (128, 256) and (self.L, H_DEC) == (self.L, 1024) and _ops.PERSIST_STATS["launches"] > 0
+        persist_b = dtype == "bf16" and self.B in (128, 256) and _ops.PERSIST_STATS["bwd_launches"] > 0
         leg = {"fwd": dict(kernel=("lstm_persist_fwd_kernel (weights-resident dataflow pass: ONE launch, time per diagonal)" if persist else
                                    "lstm_step_fwd_gm_kernel" if dtype == "bf16" and (self.B >= 1024 or self.B <= 128) else "lstm_step_fwd_kernel"),
                            us=fwd_us, flops=fwd_f, pmc_key="lstm_step_fwd"),
-               "bwd": dict(kernel=("lstm_step_bwd_kernel (fused gate-derivative epilogue)" if fused_bwd or dtype != "bf16" else
+               "bwd": dict(kernel=("lstm_persist_bwd_kernel (weights-resident dataflow pass: ONE launch, time per diagonal)" if persist_b else
+                                   "lstm_step_bwd_kernel (fused gate-derivative epilogue)" if fused_bwd or dtype != "bf16" else
                                    "lstm_step_bwd_kernel + lstm_bwd_epi_kernel (launch pair)"), us=bwd_us, flops=bwd_f, pmc_key="lstm_step_bwd")}
         by_f, by_b = lstm_step_bytes(self.B)
         leg["fwd"]["bytes"], leg["bwd"]["bytes"] = by_f * self.L / n_launch, by_b * self.L / n_launch

@@ -431,7 +431,7 @@ def test_persistent_schedule_inside_the_training_step_b128(golden_dir):
             model = mv.MolecularVAE(dtype=torch.bfloat16)
             model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
             model = model.to(dev)
-            n0 = ops.PERSIST_STATS["launches"]
+            n0, nb0 = ops.PERSIST_STATS["launches"], ops.PERSIST_STATS["bwd_launches"]
             recon, mu, logvar = model(idx, eps)
             loss = mv.bce_kl_loss(recon, ohe, mu, logvar, 120)
             loss.backward()
@@ -445,10 +445,11 @@ def test_persistent_schedule_inside_the_training_step_b128(golden_dir):
             torch.cuda.synchronize()
             ops.persist_check(sync=True)
             out[mode] = (float(loss), mu.detach().clone(), {k: p_.grad.clone() for k, p_ in model.named_parameters()}, ops.PERSIST_STATS["launches"] - n0,
-                         recon_eval.clone())
+                         recon_eval.clone(), ops.PERSIST_STATS["bwd_launches"] - nb0)
         finally:
             ops.PERSIST_DEFAULT = "1"
     assert out["1"][3] == 2 and out["0"][3] == 0
+    assert out["1"][5] == 1 and out["0"][5] == 0            # ... and the persistent decoder backward
     assert float((out["1"][4] - out["0"][4]).abs().max()) < 2e-3          # evaluation (forward-only form) reconstructions
     assert abs(out["1"][0] - out["0"][0]) < 1e-4 * abs(out["0"][0]) and abs(out["1"][0] - float(g["loss"])) < 1e-4 * float(g["loss"])
     # (the switch also selects the encoder's layer-concurrent row-resident form, whose layers >= 1 contract [x | h] in one chain instead of
@@ -457,6 +458,142 @@ def test_persistent_schedule_inside_the_training_step_b128(golden_dir):
     bad = {k: rel(out["1"][2][k].cpu().numpy(), out["0"][2][k].cpu().numpy()) for k in out["1"][2]
            if rel(out["1"][2][k].cpu().numpy(), out["0"][2][k].cpu().numpy()) > 5e-2}
     assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------- weights-resident dataflow LSTM backward (b = 128)
+def _persist_bwd_case(T, seed=0, B=128):
+    """Saved forward state from the wavefront forward, a random output gradient, and a runner for either backward schedule."""
+    from molecular_vae_amd import _lib as L
+    H, NL, PAD = 1024, 4, 64
+    G4, ldw, ldh, ldwT, ldg = 4 * H, H + PAD, H + PAD, 4 * H + PAD, 4 * H + PAD
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rnd = lambda *s: (torch.randn(*s, device=dev, generator=g) * 0.03)
+    dt = torch.bfloat16
+    Wih = [None] + [rnd(G4, ldw).to(dt) for _ in range(NL - 1)]
+    Whh = [rnd(G4, ldw).to(dt) for _ in range(NL)]
+    bias = [None] + [rnd(G4) * 10 for _ in range(NL - 1)]
+    gx0 = rnd(B, G4) * 30
+
+    def tr(w):
+        o = torch.zeros(H, ldwT, device=dev, dtype=dt)
+        o[:, :G4] = w[:, :H].t()
+        return o
+    WihT, WhhT = [None] + [tr(w) for w in Wih[1:]], [tr(w) for w in Whh]
+    hs = [torch.zeros(T, B, ldh, device=dev, dtype=dt) for _ in range(NL)]
+    cs = [torch.zeros(T, B, H, device=dev, dtype=dt) for _ in range(NL)]
+    gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
+    cstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
+    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, 0, Wih, [ldw] * NL, Whh, [ldw] * NL, bias, hs, ldh, cs, gates, cstate, persist=False)
+    dy = rnd(T, B, H) * 3
+
+    def run(persist):
+        dG = [torch.full((T, B, ldg), 7.0, device=dev, dtype=dt) for _ in range(NL)]
+        dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
+        ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, WhhT, [ldwT] * NL, WihT, [ldwT] * NL, dy.view(T * B, H), H, hs, ldh, cs, gates, dG, dstate, ldg=ldg,
+                    persist=persist)
+        torch.cuda.synchronize()
+        return dG
+    return run, (T, B, H, NL)
+
+
+def _close_rel(x, y, tol):
+    x, y = x.float(), y.float()
+    return bool(torch.isfinite(y).all()) and float((x - y).abs().max()) <= tol * float(x.abs().max())
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 120])
+def test_persistent_dataflow_lstm_backward_equals_the_wavefront_schedule(T):
+    """rnn_persist_bwd.hip (ONE launch: weights resident in registers, dG tiles and K-quarter partial sums handed between workgroups through
+    write-through stores + flag words / phase-tagged payloads) against the wavefront backward (2 x (T + 3) launches) on the same saved state
+    and output gradient at the shape it serves: every layer's pre-activation gradient within 2 bf16 steps of the buffer's largest value
+    (the two schedules add the same fp32 products in different orders); the padding columns of dG stay untouched; no failed hand-off."""
+    run, (T, B, H, NL) = _persist_bwd_case(T)
+    n0 = ops.PERSIST_STATS["bwd_launches"]
+    a, p = run(False), run(True)
+    ops.persist_check(sync=True)
+    assert ops.PERSIST_STATS["bwd_launches"] == n0 + 1
+    for l in range(NL):
+        assert _close_rel(a[l][:, :, :4 * H], p[l][:, :, :4 * H], 2.0 ** -6), l
+        assert float((p[l][:, :, 4 * H:].float() - 7.0).abs().max()) == 0.0, "padding columns written"
+
+
+def test_persistent_dataflow_backward_serves_256_rows_as_two_passes_and_is_row_position_independent():
+    """B = 256: two passes over 128 independent rows each.  The batch holds every sequence twice (rows r and 128 + r, i.e. the same row of the
+    two passes) and rows 5 and 77 of a pass are copies of each other as well: all copies must get the same BITS (the partial sums are added
+    in an order that does not depend on where a row sits)."""
+    from molecular_vae_amd import _lib as L
+    T, B, H, NL, PAD = 6, 256, 1024, 4, 64
+    G4, ldw, ldh, ldwT, ldg = 4 * H, H + PAD, H + PAD, 4 * H + PAD, 4 * H + PAD
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: (torch.randn(*s, device=dev, generator=g) * 0.03)
+    dt = torch.bfloat16
+    Wih = [None] + [rnd(G4, ldw).to(dt) for _ in range(NL - 1)]
+    Whh = [rnd(G4, ldw).to(dt) for _ in range(NL)]
+    tr = lambda w: torch.cat([w[:, :H].t().contiguous(), torch.zeros(H, PAD, device=dev, dtype=dt)], dim=1).contiguous()
+    WihT, WhhT = [None] + [tr(w) for w in Wih[1:]], [tr(w) for w in Whh]
+    half = rnd(128, G4) * 30
+    half[77] = half[5]
+    gx0 = torch.cat([half, half], 0).contiguous()
+    hs = [torch.zeros(T, B, ldh, device=dev, dtype=dt) for _ in range(NL)]
+    cs = [torch.zeros(T, B, H, device=dev, dtype=dt) for _ in range(NL)]
+    gates = [torch.zeros(T, B, G4, device=dev, dtype=dt) for _ in range(NL)]
+    cstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
+    ops.rnn_fwd(L.CELL_LSTM, dt, T, B, H, gx0, 0, Wih, [ldw] * NL, Whh, [ldw] * NL, [None] * NL, hs, ldh, cs, gates, cstate, persist=True)
+    dyh = rnd(T, 128, H) * 3
+    dyh[:, 77] = dyh[:, 5]
+    dy = torch.cat([dyh, dyh], 1).contiguous()
+    out = {}
+    for persist in (False, True):
+        dG = [torch.zeros(T, B, ldg, device=dev, dtype=dt) for _ in range(NL)]
+        dstate = [torch.zeros(2, B, H, device=dev) for _ in range(NL)]
+        ops.rnn_bwd(L.CELL_LSTM, dt, T, B, H, WhhT, [ldwT] * NL, WihT, [ldwT] * NL, dy.view(T * B, H), H, hs, ldh, cs, gates, dG, dstate, ldg=ldg,
+                    persist=persist)
+        torch.cuda.synchronize()
+        out[persist] = dG
+    ops.persist_check(sync=True)
+    for l in range(NL):
+        assert _close_rel(out[False][l][:, :, :G4], out[True][l][:, :, :G4], 2.0 ** -6), l
+        assert torch.equal(out[True][l][:, :128], out[True][l][:, 128:]), ("passes differ", l)
+        assert torch.equal(out[True][l][:, 5], out[True][l][:, 77]), ("row position", l)
+
+
+def test_persistent_dataflow_backward_counted_waits_equal_the_drained_form(monkeypatch):
+    """MVAE_PERSIST_SAFE=1 drains every group of stores at once (no counted wait ever has a store in flight): same bits."""
+    run, (T, B, H, NL) = _persist_bwd_case(24, seed=3)
+    p = run(True)
+    monkeypatch.setenv("MVAE_PERSIST_SAFE", "1")
+    q = run(True)
+    ops.persist_check(sync=True)
+    for l in range(NL):
+        assert torch.equal(p[l], q[l]), l
+
+
+def test_persistent_dataflow_backward_failed_hand_off_is_reported_not_hung(monkeypatch):
+    """Poll budget of ONE round: somebody gives up at the first flag / partial that is not there yet, every workgroup drains, the launch ends
+    and the status record becomes an MvaeError; the next launch with the normal budget is fine."""
+    run, (T, B, H, NL) = _persist_bwd_case(16, seed=5)
+    monkeypatch.setenv("MVAE_PERSIST_SPIN", "1")
+    run(True)
+    with pytest.raises(LL.MvaeError):
+        ops.persist_check(sync=True)
+    monkeypatch.delenv("MVAE_PERSIST_SPIN")
+    a, p = run(False), run(True)
+    ops.persist_check(sync=True)
+    assert _close_rel(a[0][:, :, :4 * H], p[0][:, :, :4 * H], 2.0 ** -6)
+
+
+def test_persistent_backward_back_to_back_launches_into_the_same_buffers():
+    """Six launches queued without synchronisation, different output gradients, the SAME dG / exchange / flag buffers: the last one's result
+    must be the last gradient's (a hand-off that hit a stale line or a stale phase bit of an earlier launch would reproduce old values)."""
+    from molecular_vae_amd import _lib as L
+    run, (T, B, H, NL) = _persist_bwd_case(12, seed=8)
+    a = run(False)
+    for _ in range(5):
+        run(True)
+    p = run(True)
+    ops.persist_check(sync=True)
+    for l in range(NL):
+        assert _close_rel(a[l][:, :, :4 * H], p[l][:, :, :4 * H], 2.0 ** -6), l
 
 
 # ---------------------------------------------------------------------------------------------- sampling step (mosesvae.py:236-253)
