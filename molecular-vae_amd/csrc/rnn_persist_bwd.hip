@@ -32,8 +32,8 @@ constexpr int PH = 1024, PNL = 4, PB = 128;
 constexpr int LDG = 4 * PH + 64;                  // leading dimension of the dG buffers (elements): fixed, every offset is a literal
 constexpr int PWG = 256;
 constexpr int RS = 6, SLOT = 4096, RING = RS * SLOT;
-constexpr int SCR_OFF = 4 * RING, SCR_BYTES = 12 * 4096;
-constexpr int PLDS = SCR_OFF + SCR_BYTES;         // 144 KB
+constexpr int SCR_OFF = 4 * RING, SCR_BYTES = 16 * 4096;      // reduction scratch: region (destination wave d, source wave s) at (4 d + s) x 4 KB
+constexpr int PLDS = SCR_OFF + SCR_BYTES;         // = 160 KB, all of the CU's LDS
 constexpr size_t EXCH_BYTES = (size_t)PNL * 2 * 16 * 4 * 4 * 8192;      // [layer][parity of t][blk][dst kq][src kq][plane 2][row 32][8 unit groups] float4 = 16 MB
 
 struct PersistBwdArgs {
@@ -115,8 +115,6 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
   }
   // The MFMA / LDS-exchange lane (n, q) of wave w holds, per half hf, batch row 16 (4 hf + w) + n, units 16 g + 4 q .. + 3 of the four unit
   // tiles g.  The FINALISER lane i of wave w' takes row 32 kq + 8 w' + (i >> 3), units 8 (i & 7) .. + 7 of the block's 64.
-  const int frow = 32 * kq + 8 * wave + (lane >> 3);
-  const int u0 = 64 * blk + 8 * (lane & 7);
   float dc_reg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const uint32_t ring = smem_base + (uint32_t)wave * RING;
@@ -165,65 +163,53 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
   };
   auto advance = [](uint32_t& pos) { pos = (pos == (uint32_t)((RS - 1) * SLOT)) ? 0u : pos + (uint32_t)SLOT; };
   auto step_base = [&](int tt) -> uint32_t { return (uint32_t)((tt < 0 || tt >= T) ? 0 : tt) * (uint32_t)(p.Btot * LDG * 2); };
+  // ---- K-slice exchange between the four waves + the lane re-mapping for the finaliser, in one trip through LDS.  A region holds one
+  // 16-row x 64-unit fp32 tile as [row n][16 pieces of 4 units] x 16 B, piece column XOR-swizzled with the row (col ^ n): the writer (MFMA
+  // layout: lane (n, q) holds piece 4 g + q of row n) and the reader (lane i' wants row 8 c + (i' >> 3), piece 2 (i' & 7) + pl -- what one
+  // contiguous 1 KB store of the global exchange ring needs) are both bank-conflict free.  ALL four partials go through LDS (the own one
+  // too), so every wave adds them in the order of the source wave, ((p0 + p1) + p2) + p3: row-position independent, no case distinctions.
   const uint32_t scr = smem_base + SCR_OFF;
-  const uint32_t scr_lane = scr + (uint32_t)(lane << 4);
-  auto write_partials = [&](f32x4 (&acc)[8][4], auto hc, f32x4 (&own)[4]) {       // hc: which half's four row tiles
+  // (every lane offset below is derived from an opaque copy of the lane index where it is used: kept alive across the step, the dozen of
+  // them would not fit beside 256 weight + 128 accumulator registers)
+  auto opaque_lane = [&]() -> uint32_t { uint32_t l = (uint32_t)lane; asm volatile("" : "+v"(l)); return l; };
+  auto write_partials = [&](f32x4 (&acc)[8][4], auto hc) {       // hc: which half's four row tiles
     constexpr int o = 4 * decltype(hc)::value;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      if (d == wave) continue;
-      const uint32_t base = scr_lane + (uint32_t)((3 * d + ((wave - d) & 3) - 1) << 12);
-      asm volatile("ds_write_b128 %0, %1" ::"v"(base), "v"(acc[o + d][0]) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(base), "v"(acc[o + d][1]) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(base), "v"(acc[o + d][2]) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(base), "v"(acc[o + d][3]) : "memory");
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) own[g] = wave == 0 ? acc[o][g] : wave == 1 ? acc[o + 1][g] : wave == 2 ? acc[o + 2][g] : acc[o + 3][g];
-  };
-  // sum of the four waves' K-slice partials in the order of the SOURCE wave (row-position independent, see rnn_persist.hip)
-  auto reduce_half = [&](f32x4 (&tot)[4]) {
-    const uint32_t rbase = scr_lane + (uint32_t)((wave * 3) << 12);
-    // two unit tiles at a time (24 registers of addends instead of 48: both halves' accumulators are live here)
-    auto two = [&](auto gc) {
-      constexpr int g0 = decltype(gc)::value;
-      f32x4 v[3][2];
-      v[0][0] = lds_rd<1024 * g0>(rbase); v[0][1] = lds_rd<1024 * g0 + 1024>(rbase);
-      v[1][0] = lds_rd<4096 + 1024 * g0>(rbase); v[1][1] = lds_rd<4096 + 1024 * g0 + 1024>(rbase);
-      v[2][0] = lds_rd<8192 + 1024 * g0>(rbase); v[2][1] = lds_rd<8192 + 1024 * g0 + 1024>(rbase);
-      wait_lgkmcnt<0>();
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const f32x4 o = tot[g0 + k];
-        if (wave == 0) tot[g0 + k] = ((o + v[0][k]) + v[1][k]) + v[2][k];
-        else if (wave == 1) tot[g0 + k] = ((v[2][k] + o) + v[0][k]) + v[1][k];
-        else if (wave == 2) tot[g0 + k] = ((v[1][k] + v[2][k]) + o) + v[0][k];
-        else tot[g0 + k] = ((v[0][k] + v[1][k]) + v[2][k]) + o;
-      }
-    };
-    two(std::integral_constant<int, 0>{});
-    two(std::integral_constant<int, 2>{});
-  };
-  // K-quarter partial of one half -> the exchange ring: m-tile g goes to workgroup (blk, g) (the own tile too: every reader finds four
-  // addends in one place and sums them in the same order, whoever it is)
-  // Exchange ring: per (layer, parity of t, blk, dst, src) two planes of [32 rows][8 unit groups] float4: plane pl holds units 8 u8 + 4 pl .. + 3,
-  // so that a finaliser lane's two loads are each 1 KB contiguous per wave.  The writer's pieces (unit group 2 g + (q >> 1), plane q & 1)
-  // land scattered -- 16-byte stores, the cheaper side to scatter.
-  const __amdgpu_buffer_rsrc_t r_ex = __builtin_amdgcn_make_buffer_rsrc(p.exch, 0, (int)EXCH_BYTES, 0x00020000);
-  auto ex_off = [&](int par, int dst, int src) -> uint32_t { return (uint32_t)((((((layer * 2 + par) * 16 + blk) * 4 + dst) * 4 + src)) << 13); };
-  const uint32_t ex_wr = (uint32_t)((q & 1) * 4096 + (16 * (wave & 1) + n) * 128 + (q >> 1) * 16);      // + 32 g
-  const uint32_t ex_rd = (uint32_t)(tid << 4);                                                          // + 4096 plane
-  // half hf of wave w goes to workgroup dst = 2 hf + (w >> 1) (its rows 16 (w & 1) .. + 15)
-  auto send_half = [&](int t, int hf, const f32x4 (&tot)[4]) {
-    const uint32_t ph = (uint32_t)(((T - 1 - t) >> 1) & 1);
-    const uint32_t so = ex_off(t & 1, 2 * hf + (wave >> 1), kq);
+    const uint32_t l = opaque_lane(), wn = l & 15, wq = l >> 4;
+    const uint32_t xw_base = scr + (uint32_t)(wave << 12) + (wn * 256 + ((wq ^ (wn & 3)) << 4));       // + (d << 14) + ((g << 6) ^ xw_x)
+    const uint32_t xw_x = (wn >> 2) << 6;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      u32x4_t v = __builtin_bit_cast(u32x4_t, tot[g]);
+      const uint32_t a = xw_base + (((uint32_t)g << 6) ^ xw_x);
+      asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(acc[o][g]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:16384" ::"v"(a), "v"(acc[o + 1][g]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:32768" ::"v"(a), "v"(acc[o + 2][g]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:49152" ::"v"(a), "v"(acc[o + 3][g]) : "memory");
+    }
+  };
+  // Exchange ring: per (layer, parity of t, blk, dst, src) two planes of [32 rows][8 unit groups] float4: plane pl holds units 8 u8 + 4 pl .. + 3.
+  const __amdgpu_buffer_rsrc_t r_ex = __builtin_amdgcn_make_buffer_rsrc(p.exch, 0, (int)EXCH_BYTES, 0x00020000);
+  auto ex_off = [&](int par, int dst, int src) -> uint32_t { return (uint32_t)((((((layer * 2 + par) * 16 + blk) * 4 + dst) * 4 + src)) << 13); };
+  // sum of the four K-slice partials of this wave's row tile, piece by piece in the finaliser's order, each piece straight out to the
+  // workgroup that finalises these rows: half hf of wave w goes to dst = 2 hf + (w >> 1) (its rows 16 (w & 1) .. + 15)
+  auto reduce_send_half = [&](int t, int hf) {
+    const uint32_t ph = (uint32_t)(((T - 1 - t) >> 1) & 1);
+    const uint32_t so = ex_off(t & 1, 2 * hf + (wave >> 1), kq);
+    const uint32_t l = opaque_lane();
+    const uint32_t xr_hi = scr + (uint32_t)(wave << 14) + (l >> 3) * 256;                      // + c * 2048 + (s << 12)
+    const uint32_t xr_col = (2 * (l & 7)) ^ (l >> 3);                                          // ^ (pl + 8 c), << 4
+    const uint32_t ex_wr = (uint32_t)((wave & 1) * 2048) + (l << 4);                           // + 4096 pl + 1024 c
+    auto piece = [&](auto kc) {
+      constexpr int k = decltype(kc)::value, c = k & 1, pl = k >> 1;
+      const uint32_t a = xr_hi + ((xr_col ^ (uint32_t)(pl + 8 * c)) << 4);
+      const f32x4 v0 = lds_rd<c * 2048>(a), v1 = lds_rd<c * 2048 + 4096>(a), v2 = lds_rd<c * 2048 + 8192>(a), v3 = lds_rd<c * 2048 + 12288>(a);
+      wait_lgkmcnt<0>();
+      u32x4_t v = __builtin_bit_cast(u32x4_t, ((v0 + v1) + v2) + v3);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (v[e] & ~1u) | ph;
-      store_b128_wt(v, r_ex, ex_wr, so + (uint32_t)(32 * g));
-    }
+      store_b128_wt(v, r_ex, ex_wr, so + (uint32_t)(4096 * pl + 1024 * c));
+    };
+    piece(std::integral_constant<int, 0>{}); piece(std::integral_constant<int, 1>{});
+    piece(std::integral_constant<int, 2>{}); piece(std::integral_constant<int, 3>{});
     if (p.safe) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   const __amdgpu_buffer_rsrc_t r_gates = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gates[layer]), 0, (int)((long)T * p.Btot * 4 * PH * 2), 0x00020000);
@@ -256,7 +242,7 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
     }
     const uint32_t xb = step_base(t), hb = step_base(t + 1), xb_next = step_base(t - 1);
     const uint32_t hmask = (t < T - 1) ? 0xffffffffu : 0u;
-    f32x4 acc[8][4], own0[4], own1[4];
+    f32x4 acc[8][4];
     // saved forward state of this lane's 8 cells: cold HBM reads, whole lines.  Requested in front of half 1's LDS exchange, where nothing
     // waits on the memory queue for the next ~2 us (the exchange, the partial stores, the partner workgroups' partials on their way).
     u32x4_t sg[4], sc_, scp, sdy[2];
@@ -307,20 +293,19 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
       if constexpr (refill) advance(ipos);
       if constexpr (s == E0) {
         PBWD_STAMP(3);
-        write_partials(acc, std::integral_constant<int, 0>{}, own0);
+        write_partials(acc, std::integral_constant<int, 0>{});
         wait_lgkmcnt<0>();
         raw_barrier();
-        reduce_half(own0);
-        send_half(t, 0, own0);
+        reduce_send_half(t, 0);
       }
       if constexpr (s == E1) {
         PBWD_STAMP(4);
         raw_barrier();
-        write_partials(acc, std::integral_constant<int, 1>{}, own1);
+        write_partials(acc, std::integral_constant<int, 1>{});
         {
           // (lane offsets derived here, from one opaque copy of the lane's row: kept alive across the step they would cost four registers)
-          uint32_t row0 = rowoff + (uint32_t)frow;
-          asm volatile("" : "+v"(row0));
+          const uint32_t l = opaque_lane();
+          const uint32_t row0 = rowoff + (uint32_t)(32 * kq + 8 * wave) + (l >> 3), u0 = (uint32_t)(64 * blk) + 8 * (l & 7);
           const uint32_t voff_g = (row0 * 4 * PH + u0) * 2, voff_c = (row0 * PH + u0) * 2, voff_dy = (row0 * PH + u0) * 4;
           const uint32_t hrow = (uint32_t)(t * p.Btot);
 #pragma unroll
@@ -335,8 +320,7 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
         }
         wait_lgkmcnt<0>();
         raw_barrier();
-        reduce_half(own1);
-        send_half(t, 1, own1);
+        reduce_send_half(t, 1);
       }
     };
     for_each_slot(slot_body, std::make_integer_sequence<int, NSLOT>{});
@@ -344,6 +328,7 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
     // ---- the four K-quarter partials of this workgroup's 32 rows: polled until every word carries this use's phase bit
     u32x4_t part[4][2];
     {
+      const uint32_t ex_rd = (opaque_lane() + (uint32_t)(wave << 6)) << 4;                     // + 4096 plane
       const uint32_t ph = (uint32_t)(((T - 1 - t) >> 1) & 1);
       bool got = false;
       for (uint32_t it = 0; it < p.spin_limit && !got; ++it) {
@@ -408,8 +393,8 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
         for (int k = 0; k < 4; ++k) r[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
         return r;
       };
-      uint32_t row0 = rowoff + (uint32_t)frow;
-      asm volatile("" : "+v"(row0));
+      const uint32_t l = opaque_lane();
+      const uint32_t row0 = rowoff + (uint32_t)(32 * kq + 8 * wave) + (l >> 3), u0 = (uint32_t)(64 * blk) + 8 * (l & 7);
       const uint32_t voff_dg = (row0 * LDG + u0) * 2;
       const uint32_t so = (uint32_t)(t * p.Btot) * (uint32_t)(LDG * 2);
       store_b128_wt(pack8(di), rhs, voff_dg, so);
