@@ -232,3 +232,35 @@ def test_gru_rowres_time_loops_issue_exactly_the_counted_memory_operations(tmp_p
         stores = sum(1 for i in body if i[1].startswith(("global_store", "buffer_store")))
         steps = sum(1 for i in body if i[1] == "s_barrier")            # one workgroup barrier per time step (the compiler may unroll the loop)
         assert steps >= 1 and (loads, stores) == (nld * steps, nst * steps), (key, loads, stores, steps)
+
+
+def test_no_wide_buffer_store_takes_its_offset_from_an_sgpr(tmp_path):
+    """Round-4 finding (rnn_persist_bwd.hip store_b128_wt): on gfx950 a buffer_store_dwordx4 whose soffset is an SGPR gets no wait
+    state from the compiler before a VALU instruction overwrites its data registers, and dword 1 of the stored vector was then the NEXT value.
+    Every >64-bit buffer store of the shipped library must carry a literal soffset (the compiler's hazard rule then applies); the persistent
+    kernels must also be free of scratch traffic (a scratch reload inside their slot loops would break the counted vmcnt waits)."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    lib = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(L.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib], cwd=str(tmp_path), capture_output=True, check=True)
+    wide, seen_persist = 0, 0
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" not in f:
+            continue
+        d = subprocess.run([objdump, "-d", os.path.join(str(tmp_path), f)], capture_output=True, text=True).stdout
+        for line in d.splitlines():
+            mm = re.match(r"\s*(buffer_store_dwordx[34]|buffer_store_format_xyzw?)\s+(.*?)//", line)
+            if mm:
+                wide += 1
+                ops_ = mm.group(2).replace(",", " ").split()
+                soff = [o for o in ops_ if not o.startswith(("v", "s[", "off", "idx", "sc", "nt", "lds"))]
+                assert soff and not soff[0].startswith("s"), f"SGPR soffset on a wide buffer store: {line.strip()}"
+        for key in ("lstm_persist_fwd_kernel", "lstm_persist_bwd_kernel"):
+            for m in re.finditer(r"<[^>]*" + key + r"[^>]*>:\n(.*?)s_endpgm", d, flags=re.S):
+                seen_persist += 1
+                assert "scratch_" not in m.group(1), key
+    assert wide >= 8 and seen_persist >= 3      # the backward kernel's exchange / dG stores exist and were checked; fwd<save>, fwd<no save>, bwd
