@@ -278,7 +278,8 @@ def _child(cmd, timeout=900):
     return r
 
 
-@pytest.mark.parametrize("extra", [[], ["--shard"], ["--model", "moses"]], ids=["allreduce_early_ranges", "reduce_scatter_sharded_adam", "moses_token_mean"])
+@pytest.mark.parametrize("extra", [[], ["--shard"], ["--model", "moses"], ["--persistent-shape"]],
+                         ids=["allreduce_early_ranges", "reduce_scatter_sharded_adam", "moses_token_mean", "b128_bf16_persistent_passes"])
 def test_rccl_one_rank_forced_collectives_equal_the_plain_run_bit_for_bit(tmp_path, extra):
     """train_distributed.py:72 replaced by per-process DP over RCCL: the collectives themselves, run on the ONE GPU of this box.  A fresh
     child process initialises torch.distributed with backend "nccl" (== RCCL), world_size 1, and GradSync(force=True) issues every collective
@@ -290,12 +291,17 @@ def test_rccl_one_rank_forced_collectives_equal_the_plain_run_bit_for_bit(tmp_pa
     import json
     script = os.path.join(ROOT, "tests", "dp_equiv.py")
     a, b = os.path.join(str(tmp_path), "plain.json"), os.path.join(str(tmp_path), "rccl.json")
-    base = [sys.executable, script, "--b", "32", "--steps", "4", "--dtype", "f32"] + [x for x in extra if x != "--shard"]
+    base = [sys.executable, script, "--b", "32", "--steps", "4", "--dtype", "f32"] + [x for x in extra if x not in ("--shard", "--persistent-shape")]
+    if "--persistent-shape" in extra:
+        # the per-rank shape of the 8-GPU job (B = 128, bf16): the decoder passes are the ONE-launch dataflow kernels, which need every CU --
+        # an RCCL kernel still resident when one of them starts would make it give up (MvaeError in the child); same kernels in both runs,
+        # so bit-for-bit holds in bf16 as well
+        base = [sys.executable, script, "--b", "64", "--steps", "4", "--dtype", "bf16"]
     _child(base + ["--out", a])
     _child(base + ["--out", b, "--backend", "nccl", "--force-comm"] + (["--shard"] if "--shard" in extra else []))
     ra, rb = json.load(open(a)), json.load(open(b))
     assert rb["buckets"] > 0, rb
-    if not extra:
+    if not extra or "--persistent-shape" in extra:
         assert rb["early_ranges"] == 4 * 4                       # one range per decoder LSTM layer and step, issued from the side stream
     for k in ("loss", "psum", "gnorm", "pcheck"):
         assert ra[k] == rb[k], (k, ra[k], rb[k])
