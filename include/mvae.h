@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 8
+#define MVAE_ABI_VERSION 9
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -107,6 +107,10 @@ typedef struct {
 int mvae_gemm_tn_grouped_supported(int M, int N, int64_t K, int64_t lda, int64_t ldb);
 size_t mvae_gemm_tn_grouped_workspace(int n, const mvae_gemm_tn_problem* problems);
 int mvae_gemm_tn_grouped(int n, const mvae_gemm_tn_problem* problems, void* ws, size_t ws_bytes, void* stream);
+/* The same launch with at most `max_workgroups` workgroups (0: one per tile), each looping over tiles: a throughput-bound group of GEMMs on a
+ * side stream that must leave compute units to the latency-bound launches of the main stream (the per-rank batch of a data-parallel job:
+ * K = T * b is short, the encoder's backward runs beside it). */
+int mvae_gemm_tn_grouped_capped(int n, const mvae_gemm_tn_problem* problems, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
 size_t mvae_gemm_tn_colsum_workspace(int M, int N, int K);
 int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
                         float* colsum_out, int colsum_accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = ((os.environ.get("MVAE_LIB") if os.environ.get("MVAE_TUNING", "0") not in ("", "0") else None)
             or os.path.join(_HERE, "libmvae_hip.so"))      # MVAE_LIB too is honoured only under MVAE_TUNING=1
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MVAE_F32, MVAE_BF16, MVAE_F32X3 = 0, 1, 2
 CONV_BWD_X3 = 0x100
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
@@ -99,6 +99,7 @@ SIGNATURES = {
     "mvae_gemm_tn_grouped_supported": (_i, [_i, _i, _i64, _i64, _i64]),
     "mvae_gemm_tn_grouped_workspace": (_sz, [_i, C.POINTER(GemmTnProblem)]),
     "mvae_gemm_tn_grouped": (_i, [_i, C.POINTER(GemmTnProblem), _vp, _sz, _vp]),
+    "mvae_gemm_tn_grouped_capped": (_i, [_i, C.POINTER(GemmTnProblem), _i, _vp, _sz, _vp]),
     "mvae_gemm_tn_colsum_workspace": (_sz, [_i, _i, _i]),
     "mvae_gemm_tn_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
     "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),

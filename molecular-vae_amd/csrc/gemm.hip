@@ -244,7 +244,12 @@ template <bool COLSUM>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_256_grouped_kernel(TnGroupArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
-  const int gt = xcd_remap(blockIdx.x, p.ntiles);
+  // One tile per workgroup -- or, when the launch was given fewer workgroups than tiles (a launch that must leave compute units to the kernels
+  // of another stream), a loop over tiles bt, bt + gridDim.x, ...
+#pragma unroll 1
+  for (int bt = blockIdx.x; bt < p.ntiles; bt += gridDim.x) {
+  if (bt != (int)blockIdx.x) __syncthreads();              // the previous tile's last LDS stage has been read by every wave
+  const int gt = (gridDim.x == (unsigned)p.ntiles) ? xcd_remap(bt, p.ntiles) : bt;
   int gi = 0;
 #pragma unroll 1
   for (int i = 1; i < p.ngroups; ++i) if (gt >= p.g[i].tile0) gi = i;
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_grouped_kernel(TnGroupAr
         *c = q.accumulate ? (*c + acc[i][j][r]) : acc[i][j][r];
       }
     }
+  }
 }
 // out[m] (+)= partial[0][m] + partial[1][m], fixed order
 struct TnColsumFinish { const float* partial[MVAE_MAX_LAYERS * 2]; float* out[MVAE_MAX_LAYERS * 2]; int M[MVAE_MAX_LAYERS * 2], acc[MVAE_MAX_LAYERS * 2]; int n; };
@@ -800,6 +806,9 @@ extern "C" size_t mvae_gemm_tn_grouped_workspace(int n, const mvae_gemm_tn_probl
   return b;
 }
 extern "C" int mvae_gemm_tn_grouped(int n, const mvae_gemm_tn_problem* pr, void* ws, size_t ws_bytes, void* stream) {
+  return mvae_gemm_tn_grouped_capped(n, pr, 0, ws, ws_bytes, stream);
+}
+extern "C" int mvae_gemm_tn_grouped_capped(int n, const mvae_gemm_tn_problem* pr, int max_workgroups, void* ws, size_t ws_bytes, void* stream) {
   if (n < 1 || n > MVAE_MAX_LAYERS * 2 || !pr) return MVAE_ERR_INVALID;
   if (mvae_gemm_tn_grouped_workspace(n, pr) > ws_bytes || (mvae_gemm_tn_grouped_workspace(n, pr) && !ws)) return MVAE_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -833,8 +842,10 @@ extern "C" int mvae_gemm_tn_grouped(int n, const mvae_gemm_tn_problem* pr, void*
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_grouped_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (any_cs) hipLaunchKernelGGL(gemm_tn_bf16_256_grouped_kernel<true>, dim3(tiles), dim3(512), 2 * 65536, st, a);
-  else hipLaunchKernelGGL(gemm_tn_bf16_256_grouped_kernel<false>, dim3(tiles), dim3(512), 2 * 65536, st, a);
+  int grid = tiles;
+  if (max_workgroups > 0 && max_workgroups < grid) grid = max_workgroups;
+  if (any_cs) hipLaunchKernelGGL(gemm_tn_bf16_256_grouped_kernel<true>, dim3(grid), dim3(512), 2 * 65536, st, a);
+  else hipLaunchKernelGGL(gemm_tn_bf16_256_grouped_kernel<false>, dim3(grid), dim3(512), 2 * 65536, st, a);
   MVAE_CHECK_HIP(hipGetLastError());
   if (any_cs) {
     hipLaunchKernelGGL(gemm_tn_colsum_finish_kernel, dim3((maxM + 255) / 256, f.n), dim3(256), 0, st, f);

@@ -240,9 +240,10 @@ def _params_key(params):
 
 
 DW_KSPLIT = "1"      # K-chunks of the grouped decoder weight-gradient launches (see _lstm_weight_grads)
+WGRAD_CAP = "192"      # workgroups of the grouped weight-gradient launches at small per-GPU batches (0: one per tile, released next to the encoder LSTM backward)
 
 
-def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=None):
+def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=None, max_workgroups=0):
     """dW_ih, dW_hh, db of every layer from the saved pre-activation gradients dG [T*B, 4H] and layer outputs hs [T*B, H].
     Both dtypes contract straight from the K-major buffers (bf16: hardware-transposed LDS reads; f32: exact-f32 TN kernel)."""
     G4, TB = 4 * H, Lq * B
@@ -276,7 +277,7 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
                     if k1 > lo:
                         probs.append(dict(A=a[lo:k1], B=hs[l].view(TB, ldh)[lo - B:k1 - B], out=grads[f"{prefix}.weight_hh_l{l}"], M=G4, N=H, K=k1 - lo, lda=ldg,
                                           ldb=ldh, colsum_out=db, colsum_accumulate=True, accumulate=not first))
-            ops.gemm_tn_grouped(probs)
+            ops.gemm_tn_grouped(probs, max_workgroups=max_workgroups)
         for l in layers:
             grads[f"{prefix}.bias_hh_l{l}"].copy_(grads[f"{prefix}.bias_ih_l{l}"])
         return
@@ -783,6 +784,8 @@ class _DecoderFn(torch.autograd.Function):
             parts = [list(range(nlow, NL))] + ([list(range(nlow))] if nlow >= 1 else [])
         first_name = lambda l: f"gru.weight_ih_l{l}" if l >= 1 else "gru.weight_hh_l0"
 
+        wg_cap = [0]             # workgroup cap of the grouped weight-gradient launches (0: one per tile), see the fork below
+
         def weight_grads(k):
             """part k of `parts` (None: everything at once, on the current stream)."""
             with ops._Timed("dec_lstm_wgrad" if (k is None or k == 0) else "dec_lstm_wgrad_deferred"):
@@ -798,7 +801,7 @@ class _DecoderFn(torch.autograd.Function):
                         ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
                         ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
                 layers = range(NL) if k is None else parts[k]
-                _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers)
+                _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers, max_workgroups=wg_cap[0])
                 if k is not None and dp_early:
                     # What this part produced is final on this stream: all-reduce it now -- [first parameter of its lowest layer, start of
                     # the previous part) (part 0: to the end of our range, i.e. with the head).  weight_ih_l0 / latent_input, produced on
@@ -826,8 +829,17 @@ class _DecoderFn(torch.autograd.Function):
             # earlier, the chip-filling 256 x 256 tiles only starve the peer's conv / dense backward (a 5 us bias column sum sat 308 us behind
             # them at b = 128), while next to the 32-workgroup row-resident kernel (0.7 ms) they are hidden completely.
             late_all = TB <= int(L.knob("MVAE_WGRAD_LATE_TB", 16384))      # measured: b = 128 8.38 -> 8.22 ms / step; B = 256: +0.13
-            for k in range(len(parts)):
-                fstate.park(side, (lambda kk=k: weight_grads(kk)), 1 if (late_all or 2 * k >= len(parts)) else 0)
+            # ... or, at those batches, released AT ONCE but with a capped grid (mvae_gemm_tn_grouped_capped: `cap` workgroups looping over the
+            # tiles): the compute units left over serve the peer's dependent small launches without queueing behind chip-filling tiles
+            cap = int(L.knob("MVAE_WGRAD_CAP", WGRAD_CAP)) if late_all else 0
+            if cap > 0:
+                wg_cap[0] = cap
+                for k in range(len(parts)):
+                    fstate.park(side, (lambda kk=k: weight_grads(kk)), -1)
+                fstate.run_deferred(stage=-1)
+            else:
+                for k in range(len(parts)):
+                    fstate.park(side, (lambda kk=k: weight_grads(kk)), 1 if (late_all or 2 * k >= len(parts)) else 0)
         else:
             weight_grads(None)
         # layer-0 input is time-invariant: its gradient is the time sum of dG[0]

@@ -229,9 +229,10 @@ def gemm_tn_grouped_supported(A, M, N, K, lda, ldb):
     return A.dtype == torch.bfloat16 and bool(L.load().mvae_gemm_tn_grouped_supported(M, N, K, lda, ldb))
 
 
-def gemm_tn_grouped(problems):
+def gemm_tn_grouped(problems, max_workgroups=0):
     """problems: list of dict(A, B, out, M, N, K, lda, ldb[, colsum_out, colsum_accumulate, accumulate]) -- bf16 K-major operands; ONE launch
-    for all of them, each 256 x 256 tile accumulated over its full K (no split-K slabs / reduction launch)."""
+    for all of them, each 256 x 256 tile accumulated over its full K (no split-K slabs / reduction launch).  max_workgroups > 0: that many
+    workgroups at most, looping over the tiles (leaves compute units to another stream)."""
     lib = L.load()
     n = len(problems)
     arr = (L.GemmTnProblem * n)()
@@ -245,7 +246,7 @@ def gemm_tn_grouped(problems):
         a.colsum_accumulate = 1 if q.get("colsum_accumulate") else 0
     need = lib.mvae_gemm_tn_grouped_workspace(n, arr)
     ws = Scratch.get(need, problems[0]["A"].device, tag="tn_grouped") if need else None
-    check(lib.mvae_gemm_tn_grouped(n, arr, ptr(ws), need, stream_ptr()), "mvae_gemm_tn_grouped")
+    check(lib.mvae_gemm_tn_grouped_capped(n, arr, int(max_workgroups), ptr(ws), need, stream_ptr()), "mvae_gemm_tn_grouped_capped")
 
 
 def colsum_t(X, M, N, out, ldx=None):

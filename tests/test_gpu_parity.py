@@ -28,7 +28,7 @@ def t(a, dt=torch.float32):
 
 def test_native_library_is_the_one_running():
     lib = L.load()
-    assert lib.mvae_abi_version() == L.ABI_VERSION == 8
+    assert lib.mvae_abi_version() == L.ABI_VERSION == 9
     assert os.path.samefile(L.LIB_PATH, os.path.join(ROOT, "molecular-vae_amd", "libmvae_hip.so"))
     assert any("libmvae_hip.so" in line for line in open("/proc/self/maps"))
 
@@ -213,6 +213,12 @@ def test_gemm_tn_grouped_one_launch_no_split_k():
     out2 = [torch.empty_like(o) for o in outs[:2]]
     ops.gemm_tn_grouped([dict(probs[0], out=out2[0], colsum_out=None), dict(probs[1], out=out2[1])])
     assert torch.equal(out2[0], outs[0]) and torch.equal(out2[1], outs[1])          # deterministic, independent of the grouping
+    # capped grid (mvae_gemm_tn_grouped_capped): 5 / 64 / 1000 workgroups loop over the 128 tiles -- same tiles, same bits
+    for cap in (5, 64, 1000):
+        out3 = [torch.full((M, N), float("nan"), device=dev), torch.full((M, N), float("nan"), device=dev)]
+        cs3 = torch.full((M,), float("nan"), device=dev)
+        ops.gemm_tn_grouped([dict(probs[0], out=out3[0], colsum_out=cs3), dict(probs[1], out=out3[1])], max_workgroups=cap)
+        assert torch.equal(out3[0], outs[0]) and torch.equal(out3[1], outs[1]) and torch.equal(cs3, cs0), cap
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 32), (300, 200, 513), (288, 72, 4000), (35, 1024, 1000), (120, 2304, 700), (5, 3, 7)])

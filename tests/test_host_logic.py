@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mvae.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert lib.mvae_abi_version() == L.ABI_VERSION == 8
+    assert lib.mvae_abi_version() == L.ABI_VERSION == 9
     assert lib.mvae_status_string(-2) == b"workspace too small"
 
 
