@@ -828,7 +828,7 @@ class _DecoderFn(torch.autograd.Function):
             # per-GPU batches (K = T * B short: a group of GEMMs is a few hundred microseconds) EVERYTHING waits for that second point: released
             # earlier, the chip-filling 256 x 256 tiles only starve the peer's conv / dense backward (a 5 us bias column sum sat 308 us behind
             # them at b = 128), while next to the 32-workgroup row-resident kernel (0.7 ms) they are hidden completely.
-            late_all = TB <= int(L.knob("MVAE_WGRAD_LATE_TB", 16384))      # measured: b = 128 8.38 -> 8.22 ms / step; B = 256: +0.13
+            late_all = TB <= int(L.knob("MVAE_WGRAD_LATE_TB", 32768))      # round 3: b = 128 8.38 -> 8.22 ms / step, B = 256 +0.13; with the capped grid below B = 256 gains too (9.84 -> 9.72)
             # ... or, at those batches, released AT ONCE but with a capped grid (mvae_gemm_tn_grouped_capped: `cap` workgroups looping over the
             # tiles): the compute units left over serve the peer's dependent small launches without queueing behind chip-filling tiles
             cap = int(L.knob("MVAE_WGRAD_CAP", WGRAD_CAP)) if late_all else 0
