@@ -264,3 +264,33 @@ def test_no_wide_buffer_store_takes_its_offset_from_an_sgpr(tmp_path):
                 seen_persist += 1
                 assert "scratch_" not in m.group(1), key
     assert wide >= 8 and seen_persist >= 3      # the backward kernel's exchange / dG stores exist and were checked; fwd<save>, fwd<no save>, bwd
+
+
+def test_persistent_schedule_queries_answer_not_served_without_a_256_cu_device():
+    """mvae_rnn_fwd_persist_workspace / mvae_rnn_bwd_persist_workspace: 0 = "this shape / device is not served" -- for a shape outside the one the
+    dataflow kernels serve, for a NULL descriptor, and (here: no GPU) for the served shape on a machine without a 256-CU device.  The callers
+    (ops.rnn_fwd / rnn_bwd) then keep the launch-per-diagonal schedules; asking for persist=True explicitly raises instead."""
+    lib = L.load()
+    assert lib.mvae_rnn_fwd_persist_workspace(None) == 0 and lib.mvae_rnn_bwd_persist_workspace(None) == 0
+    buf = (ctypes.c_char * 64)()
+    addr = ctypes.addressof(buf) & ~15
+    f = L.RnnFwdDesc(); b = L.RnnBwdDesc()
+    for d in (f, b):
+        d.cell, d.dtype, d.layers, d.T, d.B, d.H = L.CELL_LSTM, L.MVAE_BF16, 4, 120, 128, 1024
+    for l in range(4):
+        f.hs[l] = f.w_hh[l] = f.w_ih[l] = f.cstate[l] = addr
+        f.ldw_hh[l] = f.ldw_ih[l] = 1088
+        b.w_hhT[l] = b.w_ihT[l] = b.cs[l] = b.gates[l] = b.dG[l] = addr
+        b.ldw_hhT[l] = b.ldw_ihT[l] = 4160
+    f.ldh = 1088
+    b.ldg, b.dy, b.dy_ld = 4160, addr, 1024
+    served = (lib.mvae_rnn_fwd_persist_workspace(ctypes.byref(f)), lib.mvae_rnn_bwd_persist_workspace(ctypes.byref(b)))
+    import torch
+    if not torch.cuda.is_available():
+        assert served == (0, 0)                 # no device: not served, never an error
+    else:
+        assert served[0] in (0, 64 + 4 * 120 * 64 * 4) and (served[1] == 0 or served[1] > 16 * 1024 * 1024)
+    f.H = b.H = 512                             # another hidden size: never
+    assert lib.mvae_rnn_fwd_persist_workspace(ctypes.byref(f)) == 0 and lib.mvae_rnn_bwd_persist_workspace(ctypes.byref(b)) == 0
+    b.H = 1024; b.dy = None                     # the output gradient as a product only (dy_a): the wavefront form
+    assert lib.mvae_rnn_bwd_persist_workspace(ctypes.byref(b)) == 0
