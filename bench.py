@@ -73,6 +73,18 @@ def lstm_step_bytes(B):
     return fwd, bwd
 
 
+def lstm_persist_bytes(B):
+    """The same for the weights-resident dataflow passes (rnn_persist.hip / rnn_persist_bwd.hip: b = 128 / 256): the weights never move, so a
+    diagonal's algorithmic bytes are the hand-off operands and the saved state only -- forward: 7 x / h operands read, h + c (bf16) + gates
+    written; backward: 7 dG operands + saved gates, c, c_prev + dy (fp32, top layer) read, dG written.  (Not counted: the K-quarter partial
+    sums of the backward pass, 8 MB out + 8 MB in per diagonal at b = 128 -- traffic of this kernel's structure, not of the math; the PMC
+    figure in `traffic` has them.)"""
+    H = H_DEC
+    fwd = 7 * B * H * 2 + 4 * (B * H * 2 + B * H * 2 + B * 4 * H * 2)
+    bwd = 7 * B * 4 * H * 2 + 4 * (B * 4 * H * 2 + 2 * B * H * 2) + B * H * 4 + 4 * B * 4 * H * 2
+    return fwd, bwd
+
+
 def host_cores(cap=32):
     """Usable host cores: the affinity mask clipped by the cgroup CPU quota (an over-subscribed OpenMP team spins)."""
     n = len(os.sched_getaffinity(0))
@@ -220,12 +232,14 @@ class MolVaeWorkload:
         persist_b = dtype == "bf16" and self.B in (128, 256) and _ops.PERSIST_STATS["bwd_launches"] > 0
         leg = {"fwd": dict(kernel=("lstm_persist_fwd_kernel (weights-resident dataflow pass: ONE launch, time per diagonal)" if persist else
                                    "lstm_step_fwd_gm_kernel" if dtype == "bf16" and (self.B >= 1024 or self.B <= 128) else "lstm_step_fwd_kernel"),
-                           us=fwd_us, flops=fwd_f, pmc_key="lstm_step_fwd"),
+                           us=fwd_us, flops=fwd_f, pmc_key=("lstm_persist_fwd" if persist else "lstm_step_fwd")),
                "bwd": dict(kernel=("lstm_persist_bwd_kernel (weights-resident dataflow pass: ONE launch, time per diagonal)" if persist_b else
                                    "lstm_step_bwd_kernel (fused gate-derivative epilogue)" if fused_bwd or dtype != "bf16" else
-                                   "lstm_step_bwd_kernel + lstm_bwd_epi_kernel (launch pair)"), us=bwd_us, flops=bwd_f, pmc_key="lstm_step_bwd")}
+                                   "lstm_step_bwd_kernel + lstm_bwd_epi_kernel (launch pair)"), us=bwd_us, flops=bwd_f, pmc_key=("lstm_persist_bwd" if persist_b else "lstm_step_bwd"))}
         by_f, by_b = lstm_step_bytes(self.B)
-        leg["fwd"]["bytes"], leg["bwd"]["bytes"] = by_f * self.L / n_launch, by_b * self.L / n_launch
+        pby_f, pby_b = lstm_persist_bytes(self.B)
+        leg["fwd"]["bytes"] = (pby_f if persist else by_f) * self.L / n_launch
+        leg["bwd"]["bytes"] = (pby_b if persist_b else by_b) * self.L / n_launch
         for v in leg.values():
             v["tflops"] = v["flops"] / (v["us"] * 1e-6) / 1e12
             # BOTH floors of the launch: MFMA time of its algorithmic FLOPs, HBM time of its algorithmic bytes (bf16: intensity 250 FLOP/B at
@@ -268,7 +282,8 @@ def pmc_traffic(kernel_key, B, dtype):
             continue
         for k, v in pm.items():
             if kernel_key in k and "hbm_read_MB_corrected" in v and "hbm_write_MB" in v:
-                return (int((v["hbm_read_MB_corrected"] + v["hbm_write_MB"]) * 1024 * 1024),
+                # a persistent launch covers the whole pass: its traffic is reported per diagonal, like its time
+                return (int((v["hbm_read_MB_corrected"] + v["hbm_write_MB"]) * 1024 * 1024 / v.get("diagonals_per_launch", 1)),
                         f"profiles/{name}: off-line PMC passes over a T=16 micro-benchmark of this kernel at B={B}, full-grid launches")
     return None, None
 
