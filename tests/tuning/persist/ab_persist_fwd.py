@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Weights-resident dataflow LSTM forward (rnn_persist.hip) against the wavefront schedule at the per-rank shape of configs[2]
 (b = 128, 4 x LSTM(1024), bf16): same inputs, bit-level comparison of every output buffer, status record, time per pass and per diagonal.
-   python tests/tuning/persist/ab_persist_fwd.py [T] [reps]"""
+   python tests/tuning/persist/ab_persist_fwd.py [T] [reps] [B]"""
 import os
 os.environ.setdefault("MVAE_TUNING", "1")
 import sys
@@ -14,7 +14,8 @@ from molecular_vae_amd import ops, _lib as L   # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-B, H, NL, PAD = 128, 1024, 4, 64
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+H, NL, PAD = 1024, 4, 64
 dev = torch.device("cuda")
 dt = torch.bfloat16
 G4 = 4 * H
