@@ -588,6 +588,24 @@ def test_persistent_dataflow_backward_failed_hand_off_is_reported_not_hung(monke
     assert _close_rel(a[0][:, :, :4 * H], p[0][:, :, :4 * H], 2.0 ** -6)
 
 
+def test_persistent_backward_is_refused_off_its_shape_and_switched_by_its_knob(monkeypatch):
+    """persist=True on a shape the dataflow kernel does not serve raises (never a silent fallback when the caller asked for it); the default
+    (persist=None) follows ops.PERSIST_DEFAULT / MVAE_PERSIST_BWD (honoured under MVAE_TUNING=1, which the test session sets)."""
+    run64, _ = _persist_bwd_case(3, seed=9, B=64)
+    with pytest.raises(LL.MvaeError):
+        run64(True)
+    run, (T, B, H, NL) = _persist_bwd_case(3, seed=9)
+    n0 = ops.PERSIST_STATS["bwd_launches"]
+    a = run(None)
+    assert ops.PERSIST_STATS["bwd_launches"] == n0 + 1
+    monkeypatch.setenv("MVAE_PERSIST_BWD", "0")
+    b = run(None)
+    assert ops.PERSIST_STATS["bwd_launches"] == n0 + 1          # the wavefront schedule this time
+    ops.persist_check(sync=True)
+    for l in range(NL):
+        assert _close_rel(b[l][:, :, :4 * H], a[l][:, :, :4 * H], 2.0 ** -6), l
+
+
 def test_persistent_backward_back_to_back_launches_into_the_same_buffers():
     """Six launches queued without synchronisation, different output gradients, the SAME dG / exchange / flag buffers: the last one's result
     must be the last gradient's (a hand-off that hit a stale line or a stale phase bit of an earlier launch would reproduce old values)."""
