@@ -8,6 +8,8 @@
 //     1024 kq .. + 1023 of both W_hh^T and W_ih^T) in registers: 64 x 2048 bf16 = 256 KB, as MFMA A-fragments (wave w: k in [256 w, +256) of the
 //     quarter), and takes in only ITS quarter of the two dG blocks per step: 128 rows x 2 x 1024 k = 512 KB (the forward pass's intake), by
 //     LDS-DMA into per-wave rings, exactly the forward kernel's operand path (rnn_persist.hip);
+//     Slot order of a step: ALL x slots (the layer above is a diagonal ahead) before the h slots, so that two microseconds of work that
+//     does not depend on the layer's own flags stand between a publish and the next poll (both 64-row halves' accumulators are live);
 //   * the four K-slice partials of the waves are exchanged through LDS (as in the forward pass), which leaves the workgroup with its
 //     K-QUARTER partial of dh [128 rows x 64 units]; the four workgroups (blk, 0..3) exchange those through a 2-deep ring in global memory:
 //     workgroup kq receives BATCH ROWS 32 kq .. + 31 of all 64 units from all four, sums them in the fixed order kq = 0, 1, 2, 3, and does
