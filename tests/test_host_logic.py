@@ -294,3 +294,62 @@ def test_persistent_schedule_queries_answer_not_served_without_a_256_cu_device()
     assert lib.mvae_rnn_fwd_persist_workspace(ctypes.byref(f)) == 0 and lib.mvae_rnn_bwd_persist_workspace(ctypes.byref(b)) == 0
     b.H = 1024; b.dy = None                     # the output gradient as a product only (dy_a): the wavefront form
     assert lib.mvae_rnn_bwd_persist_workspace(ctypes.byref(b)) == 0
+
+
+def test_persistent_kernels_time_loops_issue_exactly_the_counted_memory_operations(tmp_path):
+    """The operand rings of rnn_persist.hip / rnn_persist_bwd.hip wait with counted s_waitcnt vmcnt(N): N is right only while one time step
+    issues exactly 4 LDS-DMA instructions per slot (128 per step with an x part, 64 without) and the stores the counts name -- no merged,
+    split or predicated-away access.  Disassemble the shipped library and count inside each kernel's time loops."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    lib = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(L.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib], cwd=str(tmp_path), capture_output=True, check=True)
+    found = {}
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" not in f:
+            continue
+        d = subprocess.run([objdump, "-d", os.path.join(str(tmp_path), f)], capture_output=True, text=True).stdout
+        for key in ("lstm_persist_fwd_kernelILb1E", "lstm_persist_fwd_kernelILb0E", "lstm_persist_bwd_kernel"):
+            m = re.search(r"<[^>]*" + key + r"[^>]*>:\n(.*?)s_endpgm", d, flags=re.S)
+            if not m:
+                continue
+            ins = []
+            for line in m.group(1).splitlines():
+                mm = re.match(r"\s*(\S+)\s+(.*?)//\s*([0-9A-Fa-f]+):", line)
+                if mm:
+                    ins.append((int(mm.group(3), 16), mm.group(1), mm.group(2)))
+            loops = []
+            for a, mn, ops_ in ins:
+                if mn.startswith("s_cbranch") or mn == "s_branch":
+                    try:
+                        off = int(ops_.split()[0])
+                    except ValueError:
+                        continue
+                    if off >= 32768:
+                        loops.append((a + 4 + (off - 65536) * 4, a))
+            best = {}                                # MFMAs per step -> the widest loop with that many (the time loop of that body)
+            for lo, hi in loops:
+                body = [i for i in ins if lo <= i[0] <= hi]
+                mf = sum(1 for i in body if i[1].startswith("v_mfma"))
+                if mf in (256, 512) and (mf not in best or hi - lo > best[mf][0]):
+                    best[mf] = (hi - lo, body)
+            found[key] = {mf: dict(dma=sum(1 for i in b if i[1].startswith("buffer_load") and " lds" in i[2]),
+                                   st4=sum(1 for i in b if i[1].startswith("buffer_store_dwordx4")),
+                                   st2=sum(1 for i in b if i[1].startswith("buffer_store_dwordx2")),
+                                   scratch=sum(1 for i in b if i[1].startswith("scratch_")))
+                          for mf, (_, b) in best.items()}
+    assert set(found) == {"lstm_persist_fwd_kernelILb1E", "lstm_persist_fwd_kernelILb0E", "lstm_persist_bwd_kernel"}, found.keys()
+    for key, loops_ in found.items():
+        # the body with an x part (512 MFMAs per step) must be there; the one without (layer 0 / top layer: 256) when the compiler closed its
+        # loop with a short branch this scan can see
+        assert 512 in loops_ and set(loops_) <= {256, 512}, (key, loops_.keys())
+        for mf, c in loops_.items():
+            assert c["dma"] == mf // 4 and c["scratch"] == 0, (key, mf, c)
+    # stores per step: forward with saved state 2 x (h + 4 gates + c) 8-byte stores, forward-only 2 h stores; backward 8 partial + 4 dG 16-byte stores
+    assert all(c["st2"] == 12 and c["st4"] == 0 for c in found["lstm_persist_fwd_kernelILb1E"].values()), found
+    assert all(c["st2"] == 2 and c["st4"] == 0 for c in found["lstm_persist_fwd_kernelILb0E"].values()), found
+    assert all(c["st4"] == 12 and c["st2"] == 0 for c in found["lstm_persist_bwd_kernel"].values()), found
