@@ -160,26 +160,24 @@ def spawn_ranks(args):
 class MolVaeWorkload:
     name = "MolecularVAE(i=120,o=292,c=35) ELBO train step: fwd+loss+bwd+clip(3.0)+Adam(8e-4), synthetic one-hot SMILES [B,120,35]"
 
-    def __init__(self, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB, device_eps=True):
+    def __init__(self, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB, noise="device"):
         import torch
         import molecular_vae_amd as mv
         self.mv, self.B, self.L, self.C = mv, B, L, C
-        self.device_eps = device_eps
+        self.noise = noise
         if (L, C) != (L_SEQ, VOCAB):
             self.name = self.name.replace("i=120,o=292,c=35", f"i={L},o=292,c={C}").replace("[B,120,35]", f"[B,{L},{C}]")
         torch.manual_seed(42)                                     # train.py:73
-        self.model = mv.MolecularVAE(i=L, o=LATENT, c=C, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev)
+        # Reparameterisation noise: the PRODUCT default (noise="device") draws 1e-2 * N(0, 1) inside mvae_lambda_fwd from the library's counter
+        # hash -- no bench-side override; noise="cpu" (the reference's CPU generator stream of models.py:92 through a pinned ring) is timed as
+        # secondary.headline_B1024_cpu_eps.  config.eps_source says which one a line used.
+        self.model = mv.MolecularVAE(i=L, o=LATENT, c=C, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, noise=noise).to(dev)
         self.optimizer = mv.FusedAdam(self.model.parameters(), lr=0.0008, max_grad_norm=3.0, grad_sync=sync, shard_optimizer=bool(getattr(sync, "shard_optimizer", False)))   # train.py:81,102
         self.loss_function = mv.make_loss_function(L)
         self.n_params = sum(p.numel() for p in self.model.parameters())
         g = torch.Generator().manual_seed(1234 + rank)
         self.data = torch.randint(0, C, (B, L), generator=g).to(dev)
         self.ohe = torch.nn.functional.one_hot(self.data, C).float()    # the (idx, ohe) pair MoleLoader yields, resident in HBM
-        # Reparameterisation noise.  The PRODUCT default (Lambda.draw_eps) reproduces models.py:92: scale * randn on the CPU default generator,
-        # into pinned memory, asynchronous H2D copy.  The headline workload draws it on the device instead (no host work in the step); the
-        # default form is timed as well (secondary.headline_B1024_default_eps) and config.eps_source says which one a line used.
-        if device_eps:
-            self.model.encoder.lmbd.draw_eps = lambda b, o, d: 1e-2 * torch.randn(b, o, device=d)
 
     def step(self):
         return self.mv.train_step(self.model, self.optimizer, self.loss_function, self.data, self.ohe)
@@ -265,8 +263,9 @@ class MolVaeWorkload:
     def config(self, world):
         return dict(workload=self.name, per_gpu_batch=self.B, global_batch=self.B * world, seq_len=self.L, vocab=self.C, latent=LATENT,
                     parallelism=f"dp{world}",
-                    eps_source=("device generator (bench override of Lambda.draw_eps)" if self.device_eps else
-                                "product default: CPU default generator -> pinned memory -> async H2D (models.py:92 semantics)"))
+                    eps_source=("product default, MolecularVAE(noise='device'): drawn inside mvae_lambda_fwd (counter hash + Box-Muller, explicit seed / element counter)"
+                                if self.noise == "device" else
+                                "MolecularVAE(noise='cpu'): CPU default generator -> pinned ring -> async H2D (models.py:92's RNG stream)"))
 
 
 def pmc_traffic(kernel_key, B, dtype):
@@ -288,9 +287,9 @@ def pmc_traffic(kernel_key, B, dtype):
     return None, None
 
 
-def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB, device_eps=True):
+def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB, noise="device"):
     if model == "molvae":
-        return MolVaeWorkload(B, dtype, dev, rank, sync, L, C, device_eps=device_eps)
+        return MolVaeWorkload(B, dtype, dev, rank, sync, L, C, noise=noise)
     if model == "moses":
         from bench_extra import MosesWorkload
         return MosesWorkload(B, dtype, dev, rank, sync)
@@ -298,12 +297,12 @@ def make_workload(model, B, dtype, dev, rank, sync, L=L_SEQ, C=VOCAB, device_eps
     return Models2dWorkload(B, dtype, dev, rank, sync)
 
 
-def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_SEQ, C=VOCAB, pipeline=False, device_eps=True):
+def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_SEQ, C=VOCAB, pipeline=False, noise="device"):
     """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
     import torch
     import torch.distributed as dist
     from molecular_vae_amd import ops
-    wl = make_workload(model, B, dtype, dev, rank, sync, L, C, device_eps=device_eps)
+    wl = make_workload(model, B, dtype, dev, rank, sync, L, C, noise=noise)
     log(f"[{label}] model built, per-GPU batch {B}, dtype {dtype}, world {world}")
     for i in range(warmup):
         loss = wl.step()
@@ -487,8 +486,8 @@ def main():
         # every BASELINE.json config gets a number on this line: configs[1] (B=512), the per-rank shape of configs[2] (b=128), the exact-f32
         # parity mode, configs[3] (mosesvae.VAE, B=1024) and configs[4] (L=256, C=64, B=2048 with the GB/s of its HBM-bound kernels)
         sec = {}
-        r = measure("molvae", B, "bf16", 10, 3, dev, rank, 1, None, "headline_B1024_default_eps", device_eps=False)
-        sec["headline_B1024_default_eps"] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=10, warmup=3, dtype="bf16",
+        r = measure("molvae", B, "bf16", 10, 3, dev, rank, 1, None, "headline_B1024_cpu_eps", noise="cpu")
+        sec["headline_B1024_cpu_eps"] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=10, warmup=3, dtype="bf16",
                                                  per_gpu_batch=B, eps_source=r["config"]["eps_source"])
         for label, mdl, b, dt_, st, wu, Lq, Cq in (("configs1_B512_bf16", "molvae", 512, "bf16", 10, 3, L_SEQ, VOCAB),
                                                    ("configs2_per_rank_b128_bf16", "molvae", 128, "bf16", 20, 5, L_SEQ, VOCAB),

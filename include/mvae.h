@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 9
+#define MVAE_ABI_VERSION 10
 
 #define MVAE_OK 0
 #define MVAE_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, misaligned leading dimension) */
@@ -329,9 +329,25 @@ int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream);
 /* ---------------------------------------------------------------------------------------------------------
  * Lambda / reparameterisation (K5; models.py:80-94).  mulv [B, 2*o]: mu | log_var (one stacked GEMM).
  * z = mu + exp(log_var/2) * eps        eps [B,o] is the already scaled noise (reference: 1e-2 * randn).
+ * Noise source (models.py:92 draws it on the CPU default generator; SURVEY 8b: "eps|null, seed"):
+ *   eps != NULL  the caller's noise is used as it is (parity tests, the reference's CPU RNG stream); scale / seed / offset ignored.  The pointer
+ *                may be device memory or device-mapped PINNED HOST memory (hipHostMalloc / torch pin_memory), which the launch reads in place --
+ *                no copy command in the stream; eps_out (optional) then receives a device copy for the backward pass;
+ *   eps == NULL  the draw happens INSIDE this launch: element i of the [B, o] block is scale * n(seed, offset + i), n = a standard normal
+ *                from the counter hash below (no generator state anywhere: the same (seed, offset) always yields the same block), and is
+ *                written to eps_out [B, o] (required then), which is what mvae_lambda_bwd takes as eps.
  * Backward: dmulv[:, :o] = dmu + dz ; dmulv[:, o:] = dlogvar + dz * eps * 0.5 * exp(log_var/2).
+ *
+ * The counter normal n(seed, c), c a 64-bit element counter: s = H(seed, (c >> 31) ^ 0x6A09E667), w1 = H(s, 2c mod 2^32),
+ * w2 = H(s ^ 0xBB67AE85, (2c mod 2^32) | 1) with H the counter hash of mvae_dropout_keep; u1 = ((w1 >> 8) + 0.5) / 2^24, u2 = (w2 >> 8) / 2^24,
+ * n = sqrt(-2 ln u1) * cos(2 pi u2).  mvae_normal_words returns (w1, w2) computed on the HOST by the same function the kernels compile
+ * (tests restate the draw from them); mvae_normal_fill writes out[i] = scale * n(seed, offset + i), i < n (mosesvae.py:159 / models2d.py:34
+ * randn_like as a library op).
  */
-int mvae_lambda_fwd(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar, void* stream);
+int mvae_lambda_fwd(int B, int o, const float* mulv, const float* eps, float scale, uint32_t seed, uint64_t offset, float* eps_out,
+                    float* z, float* mu, float* logvar, void* stream);
+int mvae_normal_fill(int64_t n, float scale, uint32_t seed, uint64_t offset, float* out, void* stream);
+void mvae_normal_words(uint32_t seed, uint64_t counter, uint32_t* words2);
 int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const float* dz, const float* dmu,
                     const float* dlogvar, float* dmulv, void* stream);
 
@@ -383,8 +399,9 @@ int mvae_expand_indices(const uint8_t* store, const int64_t* rows, int B, int L,
  *     bias gradients are taken from the unmasked dl first).
  */
 size_t mvae_moses_latent_workspace(int B);     /* one float per sequence: per-row KL sums, added up in a fixed order */
-int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* ws, size_t ws_bytes,
-                          void* stream);
+/* eps == NULL: eps[i] = n(seed, offset + i) is drawn in the launch and written to eps_out (see mvae_lambda_fwd). */
+int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, uint32_t seed, uint64_t offset, float* eps_out,
+                          float* z, float* kl_out, void* ws, size_t ws_bytes, void* stream);
 int mvae_moses_latent_bwd(int B, int dz, const float* mu, const float* logvar, const float* eps, const float* dz_in, const float* dkl,
                           const float* dlogvar_ext, float* dmu, float* dlogvar, void* stream);
 size_t mvae_ce_loss_workspace(int B, int T);

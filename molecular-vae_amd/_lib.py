@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = ((os.environ.get("MVAE_LIB") if os.environ.get("MVAE_TUNING", "0") not in ("", "0") else None)
             or os.path.join(_HERE, "libmvae_hip.so"))      # MVAE_LIB too is honoured only under MVAE_TUNING=1
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MVAE_F32, MVAE_BF16, MVAE_F32X3 = 0, 1, 2
 CONV_BWD_X3 = 0x100
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
@@ -119,7 +119,9 @@ SIGNATURES = {
     "mvae_conv1d_act_fwd": (_i, [_i, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "mvae_conv1d_act_bwd": (_i, [_i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "mvae_selu_bwd": (_i, [_i64, _vp, _vp, _vp]),
-    "mvae_lambda_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_lambda_fwd": (_i, [_i, _i, _vp, _vp, _f, C.c_uint32, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    "mvae_normal_fill": (_i, [_i64, _f, C.c_uint32, C.c_uint64, _vp, _vp]),
+    "mvae_normal_words": (None, [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32)]),
     "mvae_lambda_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvae_softmax_tb_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp]),
     "mvae_softmax_tb_bwd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
@@ -128,7 +130,7 @@ SIGNATURES = {
     "mvae_bce_kl_loss_bwd": (_i, [_i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "mvae_expand_indices": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mvae_moses_latent_workspace": (_sz, [_i]),
-    "mvae_moses_latent_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mvae_moses_latent_fwd": (_i, [_i, _i, _vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mvae_moses_latent_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvae_ce_loss_workspace": (_sz, [_i, _i]),
     "mvae_ce_loss_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),

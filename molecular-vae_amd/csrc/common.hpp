@@ -89,6 +89,24 @@ __host__ __device__ __forceinline__ uint32_t drop_hash_u32(uint32_t seed, uint32
   return h;
 }
 
+// Counter-based standard normal (the reparameterisation noise of models.py:92 / mosesvae.py:159 drawn inside the consuming launch): element
+// `ctr` of stream `seed` takes two words of the same hash -- the counter's high bits fold into the seed, its low 31 bits give the two
+// 32-bit counters 2c, 2c + 1 -- and Box-Muller on their top 24 bits: u1 in (0, 1) never 0, |n| <= 5.9.  normal_words() is what the host
+// restates bit for bit (mvae_normal_words, ops.normal_draw); the float transform differs from numpy's by rounding only.
+__host__ __device__ __forceinline__ void normal_words(uint32_t seed, uint64_t ctr, uint32_t& w1, uint32_t& w2) {
+  const uint32_t s = drop_hash_u32(seed, (uint32_t)(ctr >> 31) ^ 0x6A09E667u);
+  const uint32_t lo = (uint32_t)(ctr << 1);
+  w1 = drop_hash_u32(s, lo);
+  w2 = drop_hash_u32(s ^ 0xBB67AE85u, lo | 1u);
+}
+__device__ __forceinline__ float normal_draw(uint32_t seed, uint64_t ctr) {
+  uint32_t w1, w2;
+  normal_words(seed, ctr, w1, w2);
+  const float u1 = ((float)(w1 >> 8) + 0.5f) * 5.9604644775390625e-8f;      // 2^-24
+  const float u2 = (float)(w2 >> 8) * 5.9604644775390625e-8f;
+  return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -345,14 +345,23 @@ __global__ __launch_bounds__(256) void timesum_bf16x8_kernel(int T_, long BW, co
 }
 
 // ------------------------------------------------------------------------------------------- Lambda (models.py:80-94)
-__global__ __launch_bounds__(256) void lambda_fwd_kernel(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar) {
+// eps != nullptr: injected noise (device memory, or PINNED HOST memory read in place over the host link -- the "cpu" noise source needs no copy
+// command in the stream).  eps == nullptr: the draw of models.py:92 happens HERE -- element i is scale * N(0,1) from the counter hash of
+// (seed, offset + i) (common.hpp normal_draw; no generator state anywhere).  eps_out, when given, receives the noise used (what backward reads).
+__global__ __launch_bounds__(256) void lambda_fwd_kernel(int B, int o, const float* mulv, const float* eps, float scale, uint32_t seed,
+                                                         uint64_t offset, float* eps_out, float* z, float* mu, float* logvar) {
   const long n = (long)B * o;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long b = i / o; const int c = (int)(i - b * o);
     const float m = mulv[b * 2 * o + c], lv = mulv[b * 2 * o + o + c];
+    const float e = eps ? eps[i] : scale * normal_draw(seed, offset + (uint64_t)i);
+    if (eps_out) eps_out[i] = e;
     mu[i] = m; logvar[i] = lv;
-    z[i] = m + expf(lv * 0.5f) * eps[i];
+    z[i] = m + expf(lv * 0.5f) * e;
   }
+}
+__global__ __launch_bounds__(256) void normal_fill_kernel(long n, float scale, uint32_t seed, uint64_t offset, float* out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = scale * normal_draw(seed, offset + (uint64_t)i);
 }
 __global__ __launch_bounds__(256) void lambda_bwd_kernel(int B, int o, const float* mulv, const float* eps, const float* dz, const float* dmu,
                                                          const float* dlogvar, float* dmulv) {
@@ -943,15 +952,18 @@ __global__ __launch_bounds__(256) void permute102_kernel(int T_, int B, int V, c
 // z = mu + exp(logvar/2) * eps ; kl = 0.5 * mean_b sum_j (exp(logvar) + mu^2 - 1 - logvar)      (mosesvae.py:158-162)
 // one wave per sequence (row): z for the row, the row's KL sum to row_kl[b]; a second tiny launch adds the rows up in a fixed order.  (The
 // single 1024-thread block this replaces walked all B * dz elements by itself: 54 us at B = 1024 -- pure latency.)
-__global__ __launch_bounds__(256) void moses_latent_fwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z,
-                                                               float* row_kl) {
+__global__ __launch_bounds__(256) void moses_latent_fwd_kernel(int B, int dz, const float* mu, const float* logvar, const float* eps, uint32_t seed,
+                                                               uint64_t offset, float* eps_out, float* z, float* row_kl) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
   float a = 0.f;
   for (int j = lane; j < dz; j += 64) {
     const long i = (long)b * dz + j;
     const float m = mu[i], lv = logvar[i];
-    z[i] = m + expf(lv * 0.5f) * eps[i];
+    float e;                                                  // mosesvae.py:159 randn_like(mu): injected, or drawn here (see lambda_fwd_kernel)
+    if (eps) e = eps[i];
+    else { e = normal_draw(seed, offset + (uint64_t)i); eps_out[i] = e; }
+    z[i] = m + expf(lv * 0.5f) * e;
     a += expf(lv) + m * m - 1.f - lv;
   }
   a = wave_sum(a);
@@ -1199,12 +1211,12 @@ int mvae_permute102(int T, int B, int V, const float* in, float* out, void* stre
   return MVAE_OK;
 }
 size_t mvae_moses_latent_workspace(int B) { return (size_t)(B > 0 ? B : 0) * sizeof(float); }
-int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, float* z, float* kl_out, void* ws, size_t ws_bytes,
-                          void* stream) {
-  if (!mu || !logvar || !eps || !z || !kl_out || B < 1 || dz < 1) return MVAE_ERR_INVALID;
+int mvae_moses_latent_fwd(int B, int dz, const float* mu, const float* logvar, const float* eps, uint32_t seed, uint64_t offset, float* eps_out,
+                          float* z, float* kl_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!mu || !logvar || (!eps && !eps_out) || !z || !kl_out || B < 1 || dz < 1) return MVAE_ERR_INVALID;
   if (!ws || ws_bytes < mvae_moses_latent_workspace(B)) return MVAE_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(moses_latent_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, dz, mu, logvar, eps, z, (float*)ws);
+  hipLaunchKernelGGL(moses_latent_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, dz, mu, logvar, eps, seed, offset, eps_out, z, (float*)ws);
   hipLaunchKernelGGL(moses_latent_kl_kernel, dim3(1), dim3(256), 0, st, B, (const float*)ws, kl_out);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
@@ -1256,11 +1268,22 @@ int mvae_selu_bwd(int64_t n, float* dy, const float* y, void* stream) {
   return launch_selu_bwd(n, dy, y, (hipStream_t)stream);
 }
 
-int mvae_lambda_fwd(int B, int o, const float* mulv, const float* eps, float* z, float* mu, float* logvar, void* stream) {
-  if (!mulv || !eps || !z || !mu || !logvar || B < 1 || o < 1) return MVAE_ERR_INVALID;
-  hipLaunchKernelGGL(lambda_fwd_kernel, dim3(grid_for((long)B * o)), dim3(256), 0, (hipStream_t)stream, B, o, mulv, eps, z, mu, logvar);
+int mvae_lambda_fwd(int B, int o, const float* mulv, const float* eps, float scale, uint32_t seed, uint64_t offset, float* eps_out, float* z,
+                    float* mu, float* logvar, void* stream) {
+  if (!mulv || (!eps && !eps_out) || !z || !mu || !logvar || B < 1 || o < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(lambda_fwd_kernel, dim3(grid_for((long)B * o)), dim3(256), 0, (hipStream_t)stream, B, o, mulv, eps, scale, seed, offset, eps_out,
+                     z, mu, logvar);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
+}
+int mvae_normal_fill(int64_t n, float scale, uint32_t seed, uint64_t offset, float* out, void* stream) {
+  if (!out || n < 1) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(normal_fill_kernel, dim3(grid_for((long)n)), dim3(256), 0, (hipStream_t)stream, (long)n, scale, seed, offset, out);
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+void mvae_normal_words(uint32_t seed, uint64_t counter, uint32_t* words2) {
+  if (words2) normal_words(seed, counter, words2[0], words2[1]);
 }
 int mvae_lambda_bwd(int B, int o, const float* mulv, const float* eps, const float* dz, const float* dmu, const float* dlogvar,
                     float* dmulv, void* stream) {

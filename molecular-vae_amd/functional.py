@@ -65,7 +65,16 @@ class _LambdaFn(torch.autograd.Function):
         mulv = torch.empty(B, 2 * o, device=dev)
         ops.gemm_nt(xp, Wp, mulv, B, 2 * o, Kp, bias=b)
         z = torch.empty(B, o, device=dev); mu = torch.empty_like(z); logv = torch.empty_like(z)
-        ops.lambda_fwd(mulv, eps, z, mu, logv, B, o)
+        if eps is None:                     # drawn inside the launch (Lambda(noise="device"))
+            seed, off = mod.noise_stream.take(B * o)
+            eps = torch.empty(B, o, device=dev)
+            ops.lambda_fwd(mulv, None, z, mu, logv, B, o, scale=mod.scale, seed=seed, offset=off, eps_out=eps)
+        elif not torch.is_tensor(eps):      # models._HostNoise: a pinned host block, read in place by the launch
+            host, eps = eps, torch.empty(B, o, device=dev)
+            ops.lambda_fwd(mulv, host.buf, z, mu, logv, B, o, eps_out=eps)
+            host.consumed()
+        else:
+            ops.lambda_fwd(mulv, eps, z, mu, logv, B, o)
         ctx.save_for_backward(x, W, mulv, eps)
         return z, mu, logv
 
@@ -98,7 +107,9 @@ def lambda_forward(mod, x, eps=None):
     """Stand-alone Lambda (models.py:89-94) for callers that use the head outside MolEncoder."""
     B = x.shape[0]
     o = mod.z_mean.out_features
-    if eps is None:
+    if eps is None and not (mod.noise == "device" and x.is_cuda):
         eps = mod.draw_eps(B, o, x.device)
-    return _LambdaFn.apply(mod, x, eps.contiguous().float(), mod.z_mean.weight, mod.z_mean.bias,
+    if torch.is_tensor(eps):
+        eps = eps.contiguous().float().to(x.device)
+    return _LambdaFn.apply(mod, x, eps, mod.z_mean.weight, mod.z_mean.bias,
                            mod.z_log_var.weight, mod.z_log_var.bias)

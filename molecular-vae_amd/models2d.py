@@ -50,6 +50,7 @@ class VAE(nn.Module, _SavedState):
         self.gru = RNNWeights("GRU", 2, HID, NLAY)
         self.fc3 = LinearWeights(HID, VOCAB)
         self.compute_dtype = dtype
+        self.__dict__["noise_stream"] = ops.NoiseStream()           # (seed, counter) of the reparameterisation draws made inside mvae_lambda_fwd
         self._init_saved_state()
         self._pack_key, self._packed = None, {}
 
@@ -59,13 +60,11 @@ class VAE(nn.Module, _SavedState):
         B = x.shape[0]
         if tuple(x.shape[1:]) != (SEQ, VOCAB):
             raise ValueError(f"models2d.VAE expects the one-hot block [B, {SEQ}, {VOCAB}], got {tuple(x.shape)}")
-        if self.training:
-            if eps is None:
-                eps = torch.randn(B, 2, device=dev)                     # models2d.py:34 randn_like(std)
-        else:
+        if not self.training:
             eps = torch.zeros(B, 2, device=dev)                         # models2d.py:37-38: z = mu
+        # training, eps None: models2d.py:34's randn_like(std) is drawn inside mvae_lambda_fwd (counter hash of self.noise_stream)
         infer = not torch.is_grad_enabled()
-        return _Models2dFn.apply(self, x.contiguous().float(), eps.contiguous().float(), infer, *list(self.parameters()))
+        return _Models2dFn.apply(self, x.contiguous().float(), eps.contiguous().float() if eps is not None else None, infer, *list(self.parameters()))
 
     def encode(self, x):
         with torch.no_grad():
@@ -188,7 +187,12 @@ class _Models2dFn(torch.autograd.Function):
         f0 = W("f0", (B, 436)); ops.gemm_nt(flat, P["W0p"], f0, B, 435, 92, lda=12 * W3, bias=mod.fc0.bias, act=L.ACT_SELU)
         mulv = W("mulv", (B, 4)); ops.gemm_nt(f0, P["Wml"], mulv, B, 4, 436, bias=P["bml"])
         z = torch.empty(B, 2, device=dev); mu = torch.empty_like(z); logvar = torch.empty_like(z)
-        ops.lambda_fwd(mulv, eps, z, mu, logvar, B, 2)                      # :31-38 (eval mode: eps = 0 -> z = mu)
+        if eps is None:
+            seed, off = mod.noise_stream.take(B * 2)
+            eps = W("eps", (B, 2))
+            ops.lambda_fwd(mulv, None, z, mu, logvar, B, 2, scale=1.0, seed=seed, offset=off, eps_out=eps)
+        else:
+            ops.lambda_fwd(mulv, eps, z, mu, logvar, B, 2)                  # :31-38 (eval mode: eps = 0 -> z = mu)
         zp = W("zp", (B, 4)); zp[:, :2].copy_(z)
         # ---- decoder (:40-47)
         recon = _decoder_forward(mod, P, W, zp, B, dev, infer)

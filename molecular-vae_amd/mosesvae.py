@@ -73,6 +73,8 @@ class VAE(nn.Module, _SavedState):
         self.dp_group = None                 # process group of that reduction (None: the default group); moses_train_step sets it from the optimiser's GradSync
         self.last_drop_seed = None           # seed of the most recent train-mode forward (None: eval / injected mask)
         self.compute_dtype = dtype
+        self.noise = "device"                # reparameterisation noise: "device" = drawn by the library inside the latent launch; "torch" = torch.randn on the device generator
+        self.__dict__["noise_stream"] = ops.NoiseStream()
         self._init_saved_state()
         self._pack_key, self._packed = None, {}
         self.__dict__["_side"] = None
@@ -105,6 +107,19 @@ class VAE(nn.Module, _SavedState):
             return x.x_pad.to(dev, non_blocking=True), x.lengths.to(dev, non_blocking=True).to(torch.int32)
         b = pad_batch(list(x), self.pad)                              # padded where the tensors live (device tensors stay on the device)
         return b.x_pad.to(dev, non_blocking=True), b.lengths.to(dev, non_blocking=True)
+
+    def _eps(self, B, eps):
+        """The reparameterisation noise handed to the encoder node: the caller's tensor; None under noise == "device" (the library draws it
+        inside the latent launch from self.noise_stream: an explicit seed + element counter, ops.NoiseStream); torch's device generator under
+        noise == "torch" (mosesvae.py:159 as written: randn_like on the CUDA generator)."""
+        if eps is not None:
+            return eps.contiguous().float()
+        if self.noise == "device":
+            return None
+        return torch.randn(B, self.d_z, device=self.device)
+
+    def seed_noise(self, seed, counter=0):
+        self.noise_stream.reseed(seed, counter)
 
     def _draw_drop(self, T, B, drop_mask, drop_seed):
         """Train mode: the decoder GRU's inter-layer dropout draw (nn.GRU(dropout=d_dropout if d_n_layers > 1 else 0)) as (p, seed, mask | None)."""
@@ -146,22 +161,19 @@ class VAE(nn.Module, _SavedState):
         eps / drop_mask / drop_seed inject the reparameterisation noise and the train-mode inter-layer dropout draw (parity tests)."""
         x_pad, len_t = self._batch(x)
         B, T = x_pad.shape
-        if eps is None:
-            eps = torch.randn(B, self.d_z, device=self.device)         # mosesvae.py:159 randn_like(mu): device generator
+        eps = self._eps(B, eps)                                        # None: mosesvae.py:159's randn_like(mu) is drawn inside mvae_moses_latent_fwd
         drop = self._draw_drop(T, B, drop_mask, drop_seed)
         if x_pad.is_cuda and torch.is_grad_enabled():
             self._side_stream(x_pad.device)                            # first use probes for a concurrent stream: here, not inside the backward
-        kl, recon, z, logvar, y, ntok = _MosesFn.apply(self, x_pad, len_t, eps.contiguous().float(), drop, *self._plist())
+        kl, recon, z, logvar, y, ntok = _MosesFn.apply(self, x_pad, len_t, eps, drop, *self._plist())
         return kl, self._dp_token_mean(recon, ntok), z, logvar, x_pad, y
 
     def forward_encoder(self, x, eps=None):
         """mosesvae.py:142-164: x -> (z, kl_loss, logvar).  Runs the encoder half only (GRU(256), heads, reparameterisation + KL); differentiable
         w.r.t. x_emb / encoder_rnn / q_mu / q_logvar."""
         x_pad, len_t = self._batch(x)
-        if eps is None:
-            eps = torch.randn(x_pad.shape[0], self.d_z, device=self.device)
         _, params = self._half_params("enc")
-        return _MosesEncFn.apply(self, x_pad, len_t, eps.contiguous().float(), *params)
+        return _MosesEncFn.apply(self, x_pad, len_t, self._eps(x_pad.shape[0], eps), *params)
 
     def forward_decoder(self, x, z, drop_mask=None, drop_seed=None):
         """mosesvae.py:166-199: teacher-forced decoder on the caller's latent z [B, d_z] -> (recon_loss, x_padded, y); differentiable w.r.t. z
@@ -177,6 +189,9 @@ class VAE(nn.Module, _SavedState):
 
     def sample_z_prior(self, n_batch):
         """mosesvae.py:201-211 as intended (the reference reads an attribute it never sets): z ~ N(0, I)."""
+        if self.noise == "device" and self.device.type == "cuda":
+            seed, off = self.noise_stream.take(n_batch * self.d_z)
+            return ops.normal_fill(torch.empty(n_batch, self.d_z, device=self.device), 1.0, seed, off)
         return torch.randn(n_batch, self.d_z, device=self.device)
 
     @torch.no_grad()
@@ -338,8 +353,13 @@ def _enc_forward(mod, ws, P, x_pad, lengths, eps):
     ops.gemm_nt(h_last, mod.q_logvar[0].weight, l1, B, 256, Hq, bias=mod.q_logvar[0].bias, act=L.ACT_RELU)
     ops.gemm_nt(l1, mod.q_logvar[2].weight, lv, B, dz, 256, bias=mod.q_logvar[2].bias)
     z = torch.empty(B, dz, device=dev); kl = torch.empty(1, device=dev)
-    ops.moses_latent_fwd(mu, lv, eps, z, kl, B, dz)
-    return z, kl, lv
+    if eps is None:
+        seed, off = mod.noise_stream.take(B * dz)
+        eps = W("eps", (B, dz))
+        ops.moses_latent_fwd(mu, lv, None, z, kl, B, dz, seed=seed, offset=off, eps_out=eps)
+    else:
+        ops.moses_latent_fwd(mu, lv, eps, z, kl, B, dz)
+    return z, kl, lv, eps
 
 
 def _dec_forward(mod, ws, P, x_pad, lengths, z, drop):
@@ -608,7 +628,7 @@ class _MosesFn(torch.autograd.Function):
         P = mod._pack(dev)
         slot, ws, gen = mod._next_saved_ws("enc")
         dslot, dws, dgen = mod._next_saved_ws("dec")
-        z, kl, lv = _enc_forward(mod, ws, P, x_pad, lengths, eps)
+        z, kl, lv, eps = _enc_forward(mod, ws, P, x_pad, lengths, eps)
         recon, y, ntok = _dec_forward(mod, dws, P, x_pad, lengths, z, drop)
         ctx.mod, ctx.x_pad, ctx.lengths, ctx.eps, ctx.drop = mod, x_pad, lengths, eps, drop
         ctx.slot, ctx.gen, ctx.dslot, ctx.dgen = slot, gen, dslot, dgen
@@ -644,7 +664,7 @@ class _MosesEncFn(torch.autograd.Function):
         _require_cuda(dev, "mosesvae.VAE.forward_encoder")
         P = mod._pack(dev)
         slot, ws, gen = mod._next_saved_ws("enc")
-        z, kl, lv = _enc_forward(mod, ws, P, x_pad, lengths, eps)
+        z, kl, lv, eps = _enc_forward(mod, ws, P, x_pad, lengths, eps)
         ctx.mod, ctx.slot, ctx.gen, ctx.x_pad, ctx.lengths, ctx.eps = mod, slot, gen, x_pad, lengths, eps
         ctx.set_materialize_grads(False)
         return z, kl[0].clone(), lv.clone()

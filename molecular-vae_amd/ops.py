@@ -377,11 +377,13 @@ def sample_uniform(seed, step, B):
     return h.astype(np.float64) / 4294967296.0
 
 
-def moses_latent_fwd(mu, logvar, eps, z, kl, B, dz):
+def moses_latent_fwd(mu, logvar, eps, z, kl, B, dz, seed=0, offset=0, eps_out=None):
+    """eps None: the noise is drawn inside the launch from the counter hash of (seed, offset + i) and written to eps_out."""
     lib = L.load()
     need = lib.mvae_moses_latent_workspace(B)
     ws = Scratch.get(need, mu.device)
-    check(lib.mvae_moses_latent_fwd(B, dz, ptr(mu), ptr(logvar), ptr(eps), ptr(z), ptr(kl), ptr(ws), need, stream_ptr()), "mvae_moses_latent_fwd")
+    check(lib.mvae_moses_latent_fwd(B, dz, ptr(mu), ptr(logvar), ptr(eps), int(seed) & 0xFFFFFFFF, int(offset), ptr(eps_out), ptr(z), ptr(kl),
+                                    ptr(ws), need, stream_ptr()), "mvae_moses_latent_fwd")
 
 
 def moses_latent_bwd(mu, logvar, eps, dz_in, dkl, dlogvar_ext, dmu, dlogvar, B, dz):
@@ -454,8 +456,71 @@ def conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, d
                                   ptr(dx), lddx, ptr(ws), need, stream_ptr()), "mvae_conv1d_act_bwd")
 
 
-def lambda_fwd(mulv, eps, z, mu, logvar, B, o):
-    check(L.load().mvae_lambda_fwd(B, o, ptr(mulv), ptr(eps), ptr(z), ptr(mu), ptr(logvar), stream_ptr()), "mvae_lambda_fwd")
+def lambda_fwd(mulv, eps, z, mu, logvar, B, o, scale=1.0, seed=0, offset=0, eps_out=None):
+    """eps None: eps_out[i] = scale * n(seed, offset + i) is drawn inside the launch (the draw of models.py:92 as part of the op)."""
+    check(L.load().mvae_lambda_fwd(B, o, ptr(mulv), ptr(eps), float(scale), int(seed) & 0xFFFFFFFF, int(offset), ptr(eps_out), ptr(z), ptr(mu),
+                                   ptr(logvar), stream_ptr()), "mvae_lambda_fwd")
+
+
+def normal_fill(out, scale, seed, offset):
+    """out.flat[i] = scale * n(seed, offset + i): the library's counter-hash normal (randn_like without generator state)."""
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    check(L.load().mvae_normal_fill(out.numel(), float(scale), int(seed) & 0xFFFFFFFF, int(offset), ptr(out), stream_ptr()), "mvae_normal_fill")
+    return out
+
+
+def normal_draw(seed, offset, n, scale=1.0):
+    """Host restatement (numpy, float64) of the n normals the kernels draw for counters offset .. offset + n - 1 of stream `seed`
+    (include/mvae.h: mvae_lambda_fwd).  The hash words are bit-exact (tests hold them to mvae_normal_words); the transform is in double."""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFF)
+
+    def H(seed_, idx):
+        h = ((idx * np.uint64(0x9E3779B1)) & M) ^ seed_
+        h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & M
+        h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & M
+        h ^= h >> np.uint64(16)
+        return h
+    c = np.uint64(offset) + np.arange(n, dtype=np.uint64)
+    s = H(np.uint64(seed & 0xFFFFFFFF), (c >> np.uint64(31)) ^ np.uint64(0x6A09E667))
+    lo = (c << np.uint64(1)) & M
+    w1 = H(s, lo)
+    w2 = H(s ^ np.uint64(0xBB67AE85), lo | np.uint64(1))
+    u1 = ((w1 >> np.uint64(8)).astype(np.float64) + 0.5) / 16777216.0
+    u2 = (w2 >> np.uint64(8)).astype(np.float64) / 16777216.0
+    return scale * np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2), w1.astype(np.uint32), w2.astype(np.uint32)
+
+
+class NoiseStream:
+    """One device-side normal stream: an explicit 32-bit seed and a running 64-bit element counter -- all the state there is (picklable; a
+    checkpoint may carry `state()`).  take(n) hands out the (seed, offset) of the next n elements.  The default seed comes from
+    torch.initial_seed() (so torch.manual_seed makes a run reproducible), the rank of the default process group (ranks draw different noise
+    for their shards) and a per-process instance number (two models in one process draw different streams)."""
+    _instances = [0]
+
+    def __init__(self, seed=None):
+        self.seed, self.counter = seed, 0
+
+    def _default_seed(self):
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        NoiseStream._instances[0] += 1
+        words = (C.c_uint32 * 2)()
+        L.load().mvae_normal_words(torch.initial_seed() & 0xFFFFFFFF, (rank << 20) + NoiseStream._instances[0], words)
+        return int(words[0])
+
+    def reseed(self, seed, counter=0):
+        self.seed, self.counter = int(seed) & 0xFFFFFFFF, int(counter)
+
+    def take(self, n):
+        if self.seed is None:
+            self.seed = self._default_seed()
+        off = self.counter
+        self.counter += int(n)
+        return self.seed, off
+
+    def state(self):
+        return dict(seed=self.seed, counter=self.counter)
 
 
 def lambda_bwd(mulv, eps, dz, dmu, dlogvar, dmulv, B, o):

@@ -57,7 +57,6 @@ loss_fn = mv.make_loss_function(120)
 g = torch.Generator().manual_seed(1234)
 data = torch.randint(0, 35, (args.batch, 120), generator=g).to(dev)
 ohe = torch.nn.functional.one_hot(data, 35).float()
-model.encoder.lmbd.draw_eps = lambda b, o, d: 1e-2 * torch.randn(b, o, device=d)
 keys = sorted({k for s in settings for k in s})
 
 

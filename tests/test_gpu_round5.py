@@ -1,0 +1,160 @@
+"""GPU parity tests added in round 5 (-m gpu).
+
+* the reparameterisation draw of models.py:92 / mosesvae.py:159 / models2d.py:34 as a LIBRARY op (mvae_lambda_fwd / mvae_moses_latent_fwd with
+  eps == NULL, mvae_normal_fill): equal to the host restatement of the counter hash, reproducible from (seed, counter), statistically
+  N(0, scale^2), and -- the parity statement -- a step that draws on the device equals the same step with the restated noise INJECTED;
+* the "cpu" source keeps the reference's CPU generator stream through a pinned ring.
+Checker = oracle/ (numpy) and the host restatements in molecular_vae_amd.ops."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import gpu_helpers as gh
+    from gpu_helpers import O, ip, mv, rel
+    from molecular_vae_amd import ops, _lib as LL
+    dev = torch.device("cuda", 0)
+
+
+# ---------------------------------------------------------------------------------------------- device-side reparameterisation noise
+def test_normal_fill_equals_the_host_restatement_and_is_normal():
+    """mvae_normal_fill: every element equals scale * n(seed, offset + i) of the numpy restatement (hash words bit-exact on the host test; the
+    float transform to 2e-6 absolute in units of sigma), across the 2^31 counter fold; moments and a Kolmogorov-Smirnov test against
+    N(0, 1e-4) (= models.py:92's 1e-2 * randn) at the headline size B x o = 1024 x 292."""
+    from scipy import stats
+    for seed, off, n in ((1234, 0, 1024 * 292), (7, (1 << 31) - 1000, 4096), (0xFFFFFFFF, (1 << 45) + 3, 4096)):
+        out = ops.normal_fill(torch.empty(n, device=dev), 1e-2, seed, off).cpu().numpy().astype(np.float64)
+        want, _, _ = ops.normal_draw(seed, off, n, scale=1e-2)
+        assert np.abs(out - want).max() < 2e-6 * 1e-2 * 6, (seed, off, np.abs(out - want).max())
+    x = ops.normal_fill(torch.empty(1024 * 292, device=dev), 1e-2, 1234, 0).cpu().numpy().astype(np.float64)
+    n = x.size
+    assert abs(x.mean()) < 4 * 1e-2 / np.sqrt(n) and abs(x.std() / 1e-2 - 1) < 6e-3
+    assert stats.kstest(x / 1e-2, "norm").pvalue > 1e-3
+    a = ops.normal_fill(torch.empty(1000, device=dev), 1.0, 5, 100)
+    b = ops.normal_fill(torch.empty(2000, device=dev), 1.0, 5, 0)
+    assert torch.equal(a, b[100:1100])                     # a draw depends on (seed, counter) only, not on the launch shape
+
+
+def test_lambda_draws_its_noise_inside_the_launch():
+    """Lambda(noise="device") (the default): z = mu + exp(log_v / 2) * scale * n(seed, counter) with the restated normals; the same seed
+    reproduces z bit for bit, the counter advances by B * o per forward, gradients use the drawn block (formulas in float64)."""
+    torch.manual_seed(3)
+    lam = mv.Lambda(i=435, o=292, scale=1e-2).to(dev)
+    assert lam.noise == "device"
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((9, 435)); gz = rs.standard_normal((9, 292))
+    tx = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    lam.seed_noise(77)
+    z, mu, lv = lam(tx)
+    assert lam.noise_stream.state() == dict(seed=77, counter=9 * 292)
+    eps, _, _ = ops.normal_draw(77, 0, 9 * 292, scale=1e-2)
+    eps = eps.reshape(9, 292)
+    Wm, bm = lam.z_mean.weight.detach().double().cpu().numpy(), lam.z_mean.bias.detach().double().cpu().numpy()
+    Wv, bv = lam.z_log_var.weight.detach().double().cpu().numpy(), lam.z_log_var.bias.detach().double().cpu().numpy()
+    rmu, rlv = x @ Wm.T + bm, x @ Wv.T + bv
+    assert rel(z.detach().cpu().numpy(), rmu + np.exp(rlv / 2) * eps) < 1e-5
+    assert np.abs((z - mu).detach().cpu().numpy() / np.exp(rlv / 2) - eps).max() < 2e-6      # the noise itself, not hidden under mu
+    (z * torch.tensor(gz, device=dev).float()).sum().backward()
+    dlv = gz * eps * 0.5 * np.exp(rlv / 2)
+    assert rel(lam.z_log_var.weight.grad.cpu().numpy(), dlv.T @ x) < 1e-5 and rel(lam.z_mean.weight.grad.cpu().numpy(), gz.T @ x) < 1e-5
+    z2, _, _ = lam(tx.detach())                                    # next block of the stream: different noise
+    assert not torch.equal(z2, z.detach())
+    eps2, _, _ = ops.normal_draw(77, 9 * 292, 9 * 292, scale=1e-2)
+    assert rel(z2.detach().cpu().numpy(), rmu + np.exp(rlv / 2) * eps2.reshape(9, 292)) < 1e-5
+    lam.seed_noise(77)
+    z3, _, _ = lam(tx.detach())
+    assert torch.equal(z3, z.detach())                             # bit-reproducible from (seed, counter)
+    # the "cpu" source: scale * randn on the CPU default generator (models.py:92), through the pinned ring -- more draws than ring slots
+    lam.noise = "cpu"
+    torch.manual_seed(123)
+    zs = [lam(tx.detach())[0].detach().cpu() for _ in range(mv.Lambda.EPS_RING + 2)]
+    torch.manual_seed(123)
+    for zc in zs:
+        want = 1e-2 * torch.randn(9, 292)
+        assert torch.allclose(zc, torch.tensor(rmu + np.exp(rlv / 2) * want.double().numpy()).float(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_molecular_vae_step_with_device_noise_equals_the_step_with_that_noise_injected(dtype):
+    """MolecularVAE (product default, noise drawn inside mvae_lambda_fwd) against the SAME model fed the host restatement of that draw as
+    `eps`: loss, mu, logvar, recon and every gradient agree to fp32 rounding of eps (the injected path is the one the fixtures pin), for two
+    consecutive steps (the second uses the next counter block)."""
+    torch.manual_seed(11)
+    model = mv.MolecularVAE(dtype=dtype).to(dev)
+    assert model.encoder.lmbd.noise == "device"
+    loss_fn = mv.make_loss_function(120)
+    B = 16
+    idx = torch.randint(0, 35, (B, 120), generator=torch.Generator().manual_seed(5)).to(dev)
+    ohe = torch.nn.functional.one_hot(idx, 35).float()
+    model.encoder.lmbd.seed_noise(2024)
+    for step in range(2):
+        outs = []
+        for inject in (False, True):
+            model.zero_grad(set_to_none=True)
+            if inject:
+                e, _, _ = ops.normal_draw(2024, step * B * 292, B * 292, scale=1e-2)
+                recon, mu, lv = model(idx, eps=torch.tensor(e.reshape(B, 292), dtype=torch.float32, device=dev))
+            else:
+                recon, mu, lv = model(idx)
+            loss = loss_fn(recon, ohe, mu, lv)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((float(loss), mu.detach().cpu().numpy(), recon.detach().cpu().numpy(),
+                         {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}))
+        (la, mua, ra, ga), (lb, mub, rb, gb) = outs
+        tol = 1e-5 if dtype == torch.float32 else 2e-3       # bf16: an eps difference of 1 fp32 ulp can flip a bf16 rounding downstream
+        assert abs(la - lb) < 1e-6 * abs(lb) + (0 if dtype == torch.float32 else 1e-5 * abs(lb))
+        assert np.array_equal(mua, mub) and rel(ra, rb) < tol
+        bad = {k: rel(ga[k], gb[k]) for k in ga if rel(ga[k], gb[k]) > 10 * tol}
+        assert not bad, bad
+    assert model.encoder.lmbd.noise_stream.counter == 2 * B * 292     # injected forwards consume nothing
+
+
+def test_moses_and_models2d_draw_their_noise_in_the_library(golden_dir):
+    """mosesvae.VAE (mosesvae.py:159 randn_like) and models2d.VAE (models2d.py:34): the default forward draws inside the latent launch; it
+    equals the forward with the restated normals injected, and is reproducible from the seed."""
+    from test_gpu_parity import _moses_setup
+    g, model, params = _moses_setup(golden_dir, torch.float32)
+    assert model.noise == "device"
+    seqs = [torch.from_numpy(g[f"seq{b}"]) for b in range(6)]
+    model.seed_noise(31)
+    kl, recon, z, lv, _, y = model(seqs)
+    model.zero_grad(set_to_none=True); (kl + recon).backward(); torch.cuda.synchronize()
+    ga = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+    e, _, _ = ops.normal_draw(31, 0, 6 * 160)
+    kl2, recon2, z2, lv2, _, y2 = model(seqs, eps=torch.tensor(e.reshape(6, 160), dtype=torch.float32, device=dev))
+    model.zero_grad(set_to_none=True); (kl2 + recon2).backward(); torch.cuda.synchronize()
+    assert abs(float(kl) - float(kl2)) < 1e-6 * abs(float(kl2)) and abs(float(recon) - float(recon2)) < 1e-5 * abs(float(recon2))
+    assert rel(z.detach().cpu().numpy(), z2.detach().cpu().numpy()) < 1e-5
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert rel(ga[k], p.grad.cpu().numpy()) < 1e-4, k
+    model.seed_noise(31)
+    z3 = model.forward_encoder(seqs)[0]
+    assert torch.equal(z3.detach(), z.detach())
+    zp = model.sample_z_prior(64)
+    want, _, _ = ops.normal_draw(31, 6 * 160, 64 * 160)
+    assert np.abs(zp.cpu().numpy().reshape(-1) - want).max() < 1e-5
+    model.noise = "torch"
+    torch.manual_seed(9); za = model.forward_encoder(seqs)[0]
+    torch.manual_seed(9); zb = model.forward_encoder(seqs)[0]
+    assert torch.equal(za, zb) and not torch.equal(za.detach(), z.detach())
+    # models2d
+    from molecular_vae_amd import models2d
+    torch.manual_seed(4)
+    m2 = models2d.VAE().to(dev).train()
+    x = torch.nn.functional.one_hot(torch.randint(0, models2d.VOCAB, (8, models2d.SEQ), generator=torch.Generator().manual_seed(1)), models2d.VOCAB).float().to(dev)
+    m2.noise_stream.reseed(17)
+    ra, mua, lva = m2(x)
+    e2, _, _ = ops.normal_draw(17, 0, 16)
+    rb, mub, lvb = m2(x, eps=torch.tensor(e2.reshape(8, 2), dtype=torch.float32, device=dev))
+    assert torch.equal(mua, mub) and rel(ra.detach().cpu().numpy(), rb.detach().cpu().numpy()) < 2e-3

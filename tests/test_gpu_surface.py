@@ -154,7 +154,9 @@ def test_standalone_lambda_head_vs_numpy():
     assert rel(lam.z_mean.weight.grad.cpu().numpy(), dmu.T @ x) < 1e-5 and rel(lam.z_mean.bias.grad.cpu().numpy(), dmu.sum(0)) < 1e-5
     assert rel(lam.z_log_var.weight.grad.cpu().numpy(), dlv.T @ x) < 1e-5 and rel(lam.z_log_var.bias.grad.cpu().numpy(), dlv.sum(0)) < 1e-5
     assert rel(tx.grad.cpu().numpy(), dmu @ Wm + dlv @ Wv) < 1e-5
-    # without eps the draw is scale * randn on the CPU default generator (models.py:92): reproducible under manual_seed
+    # noise="cpu": without eps the draw is scale * randn on the CPU default generator (models.py:92): reproducible under manual_seed
+    # (the default source, "device", is covered by tests/test_gpu_round5.py)
+    lam.noise = "cpu"
     torch.manual_seed(123); z1, _, _ = lam(tx.detach())
     torch.manual_seed(123); want = 1e-2 * torch.randn(9, 292)
     assert torch.allclose(z1.cpu(), torch.tensor(rmu + np.exp(rlv / 2) * want.double().numpy()).float(), rtol=1e-4, atol=1e-6)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mvae.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert lib.mvae_abi_version() == L.ABI_VERSION == 9
+    assert lib.mvae_abi_version() == L.ABI_VERSION == int(re.search(r"#define MVAE_ABI_VERSION (\d+)", header).group(1))
     assert lib.mvae_status_string(-2) == b"workspace too small"
 
 
@@ -44,6 +44,53 @@ def test_struct_layout_matches_header():
     m = ops.dropout_keep_mask(12345, (2, 3, 5, 8), 0.2).reshape(-1)
     assert [lib.mvae_dropout_keep(12345, i, 0.2) for i in range(m.size)] == m.tolist()
     assert 0.7 < ops.dropout_keep_mask(7, (1, 50, 40, 64), 0.2).mean() < 0.9
+
+
+def test_counter_normal_host_restatement_and_distribution():
+    """The reparameterisation noise the kernels draw (mvae_lambda_fwd with eps == NULL): the numpy restatement's hash words equal the ones the
+    library's own host-compiled function returns (same source as the device code), across the 2^31 counter fold; the normals they make pass
+    moment / Kolmogorov-Smirnov / lag-correlation checks; streams of different seeds and disjoint offsets are uncorrelated."""
+    from scipy import stats
+    lib = L.load()
+    w = (ctypes.c_uint32 * 2)()
+    for seed, off in ((0, 0), (42, 7), (0xDEADBEEF, (1 << 31) - 3), (5, (1 << 40) + 12345), (0xFFFFFFFF, (1 << 63) + 9)):
+        _, w1, w2 = ops.normal_draw(seed, off, 8)
+        for k in range(8):
+            lib.mvae_normal_words(seed, off + k, w)
+            assert (int(w[0]), int(w[1])) == (int(w1[k]), int(w2[k])), (seed, off, k)
+    n = 1 << 20
+    x, _, _ = ops.normal_draw(1234, 0, n)
+    assert abs(x.mean()) < 4 / np.sqrt(n) and abs(x.std() - 1) < 4e-3
+    assert abs(stats.skew(x)) < 0.01 and abs(stats.kurtosis(x)) < 0.02
+    assert stats.kstest(x, "norm").pvalue > 1e-3
+    assert np.abs(x).max() < 5.9
+    for lag in (1, 2, 292, 1024):                       # neighbouring elements, neighbouring rows (o = 292), a power of two
+        assert abs(np.corrcoef(x[:-lag], x[lag:])[0, 1]) < 5 / np.sqrt(n)
+    y, _, _ = ops.normal_draw(1235, 0, n)               # neighbouring seed
+    z_, _, _ = ops.normal_draw(1234, n, n)              # the next block of the same stream
+    assert abs(np.corrcoef(x, y)[0, 1]) < 5 / np.sqrt(n) and abs(np.corrcoef(x, z_)[0, 1]) < 5 / np.sqrt(n)
+    a, _, _ = ops.normal_draw(1234, 100, 50, scale=1e-2)
+    assert np.allclose(a, 1e-2 * x[100:150], rtol=1e-14, atol=0)     # a draw depends on (seed, counter) only
+
+
+def test_noise_stream_and_cpu_noise_source():
+    """ops.NoiseStream hands out consecutive counter ranges of one seeded stream; Lambda(noise="cpu") consumes the CPU default generator exactly
+    as models.py:92 does (scale * torch.randn(B, o))."""
+    torch.manual_seed(7)
+    s1 = ops.NoiseStream(); a = s1.take(10); b = s1.take(5)
+    assert a[0] == b[0] and (a[1], b[1]) == (0, 10) and s1.state() == dict(seed=a[0], counter=15)
+    torch.manual_seed(7)
+    s2 = ops.NoiseStream()
+    assert s2.take(1)[0] != a[0]                         # a second stream of the same process: another seed
+    s2.reseed(99, 1 << 40); assert s2.take(3) == (99, 1 << 40) and s2.take(1) == (99, (1 << 40) + 3)
+    lam = M.Lambda(8, 5, noise="cpu")
+    torch.manual_seed(3); e = lam.draw_eps(4, 5, torch.device("cpu"))
+    torch.manual_seed(3); ref = 1e-2 * torch.randn(4, 5)
+    assert torch.equal(e, ref)
+    with pytest.raises(ValueError):
+        M.Lambda(8, 5, noise="gpu")
+    assert M.Lambda(8, 5).noise == "device" and mv.MolecularVAE().encoder.lmbd.noise == "device"
+    assert mv.MolecularVAE(noise="cpu").encoder.lmbd.noise == "cpu"
 
 
 def test_state_dict_keys_and_shapes_match_reference_layout():
