@@ -214,15 +214,24 @@ typedef struct {
    * (a workgroup was not resident, or a producer died), the outputs are invalid; the launch itself always ends.
    * The narrow exact-f32 stacks (LSTM, H = 72: the encoder, models.py:117,128) use the same scratch for their LAYER-CONCURRENT row-resident form
    * (rnn_rowres.hip: all layers in one launch as a pipeline over per-workgroup progress words, when layers x ceil(B / 4) workgroups are resident
-   * at once); same status convention. */
+   * at once); same status convention.
+   * poison (optional, device fp32 word): a launch of this call that gives up ALSO stores a quiet NaN there -- the caller points it at the
+   * spare slot behind its flat gradient buffer, so that mvae_sumsq / mvae_clip_adam skip the whole update of a step whose forward or
+   * backward pass produced garbage (and, in data parallel, every rank skips it: the slot travels with the gradient all-reduce).  Nothing
+   * is ever written there by a launch that succeeds. */
   void* persist_ws; size_t persist_ws_bytes;
+  float* poison;
+  int no_spin;         /* != 0: never take a schedule that contains bounded spins (the caller's fallback after a launch that gave up) */
 } mvae_rnn_fwd_desc;
 
 /* keep decision of the device-generated dropout mask (host-callable restatement: the oracle and the tests use the same hash):
  *   h = idx * 0x9E3779B1 ^ seed; h ^= h >> 16; h *= 0x85EBCA6B; h ^= h >> 13; h *= 0xC2B2AE35; h ^= h >> 16;  keep = h >= (uint32)(p * 2^32) */
 int mvae_dropout_keep(uint32_t seed, uint32_t idx, float p);
 
-int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream);
+/* status_out (optional): receives the device address of the 16-byte status record the launches THIS call enqueued will leave behind (word 0
+ * != 0: a bounded spin ran out, the outputs are invalid; words 1-2: who), or NULL when the schedule it took contains no bounded spin (the
+ * wavefront and layer-by-layer schedules: nothing to check).  The library, not the caller, knows which schedule ran. */
+int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream, const void** status_out);
 size_t mvae_rnn_fwd_persist_workspace(const mvae_rnn_fwd_desc* d);   /* 0: this shape / device is not served by the persistent schedule */
 
 /* Backward through time of the same stack (reverse wavefront).  One launch computes, per cell,
@@ -267,11 +276,14 @@ typedef struct {
    * LSTM, bf16, 4 layers, H = 1024, B = 128 (256: two passes), ldg = 4H + 64, the output gradient given as dy (fp32, dy_ld = H; not dy_a), no
    * dh_last / dropout, on a 256-CU device with nothing else running beside it: mvae_rnn_bwd_persist_workspace() returns 0 for everything else.
    * persist_ws != NULL (that many bytes, 16-byte aligned) selects it; its first 16 bytes are the status record (word 0 != 0: a bounded spin
-   * ran out, dG is invalid).  dstate is not written by this schedule (the carried dc never leaves the registers). */
+   * ran out, dG is invalid).  dstate is not written by this schedule (the carried dc never leaves the registers).
+   * poison: as in mvae_rnn_fwd_desc (also honoured by the layer-concurrent row-resident backward, whose status record lives inside split_ws). */
   void* persist_ws; size_t persist_ws_bytes;
+  float* poison;
+  int no_spin;         /* as in mvae_rnn_fwd_desc */
 } mvae_rnn_bwd_desc;
 
-int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream);
+int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream, const void** status_out);     /* status_out: see mvae_rnn_fwd */
 size_t mvae_rnn_bwd_persist_workspace(const mvae_rnn_bwd_desc* d);   /* 0: this shape / device is not served by the persistent schedule */
 /* bytes of split_ws that let mvae_rnn_bwd pick any of its schedules for this shape (reads layers, T, B, H only). */
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d);
@@ -428,12 +440,16 @@ int mvae_mask_rows_tb(int dtype, int T, int B, int64_t ld, const int32_t* length
  *   produced on device by mvae_clip_adam itself from `partial` (no host synchronisation).
  *   coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping); grads are scaled by
  *   grad_scale first (1/world_size after an all-reduce SUM).
+ *   A step whose global norm is NOT FINITE is skipped as a whole: p, m, v stay as they are and norm_out[1] (when norm_out has room for it:
+ *   norm_out_len >= 2) is incremented by one.  That is how a failed persistent launch (mvae_rnn_*_desc.poison -> a NaN in a slot of g that
+ *   mvae_sumsq covers) keeps the weights intact without any host synchronisation; the reference would turn every parameter into NaN at
+ *   such a step (clip_grad_norm_ scales by NaN).  poison_reset (optional): that slot, set back to 0 by the launch for the next step.
  */
 size_t mvae_sumsq_workspace(int64_t n);
 int mvae_sumsq(int64_t n, const float* g, float* partial, void* stream);
 int mvae_clip_adam(int64_t n, float* p, const float* g, float* m, float* v, const float* partial, int64_t npartial,
                    float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, int step,
-                   float* norm_out, void* stream);
+                   float* norm_out, int norm_out_len, float* poison_reset, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,7 +39,7 @@ class RnnFwdDesc(C.Structure):
                 ("cstate", _vp * MAX_LAYERS),
                 ("zero_padded_k", _i),
                 ("hdrop", _vp * MAX_LAYERS), ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32),
-                ("persist_ws", _vp), ("persist_ws_bytes", _sz)]
+                ("persist_ws", _vp), ("persist_ws_bytes", _sz), ("poison", _vp), ("no_spin", _i)]
 
 
 class RnnBwdDesc(C.Structure):
@@ -60,7 +60,7 @@ class RnnBwdDesc(C.Structure):
                 ("dh0", _vp * MAX_LAYERS),
                 ("split_ws", _vp), ("split_ws_bytes", _sz),
                 ("drop_mask", _vp * MAX_LAYERS), ("drop_p", _f), ("drop_seed", C.c_uint32),
-                ("persist_ws", _vp), ("persist_ws_bytes", _sz)]
+                ("persist_ws", _vp), ("persist_ws_bytes", _sz), ("poison", _vp), ("no_spin", _i)]
 
 
 class GemmTnProblem(C.Structure):
@@ -91,7 +91,7 @@ SIGNATURES = {
     "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_onehot_tb": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp]),
-    "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp]),
+    "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp, C.POINTER(_vp)]),
     "mvae_rnn_fwd_persist_workspace": (_sz, [C.POINTER(RnnFwdDesc)]),
     "mvae_dropout_keep": (_i, [C.c_uint32, C.c_uint32, _f]),
     "mvae_gemm_tn_f32_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
@@ -102,7 +102,7 @@ SIGNATURES = {
     "mvae_gemm_tn_grouped_capped": (_i, [_i, C.POINTER(GemmTnProblem), _i, _vp, _sz, _vp]),
     "mvae_gemm_tn_colsum_workspace": (_sz, [_i, _i, _i]),
     "mvae_gemm_tn_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
-    "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp]),
+    "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp, C.POINTER(_vp)]),
     "mvae_rnn_bwd_workspace": (_sz, [C.POINTER(RnnBwdDesc)]),
     "mvae_rnn_bwd_persist_workspace": (_sz, [C.POINTER(RnnBwdDesc)]),
     "mvae_rowsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i, _vp]),
@@ -141,7 +141,7 @@ SIGNATURES = {
     "mvae_mask_rows_tb": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp]),
     "mvae_sumsq_workspace": (_sz, [_i64]),
     "mvae_sumsq": (_i, [_i64, _vp, _vp, _vp]),
-    "mvae_clip_adam": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
+    "mvae_clip_adam": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp, _i, _vp, _vp]),
 }
 
 _lib = None
@@ -228,8 +228,19 @@ PARAM_EPOCH = [0]
 _SINK_ATTR = "_mvae_sink"
 
 
-def register_grad_sink(p, owner, flat, off):
-    setattr(p, _SINK_ATTR, (weakref.ref(owner), flat, off, p.numel()))
+def register_grad_sink(p, owner, flat, off, poison=None):
+    """poison: the spare fp32 slot behind the flat gradient buffer (FusedAdam): a persistent launch that gives up stores a NaN there, which
+    makes mvae_clip_adam skip the step (mvae_rnn_*_desc.poison)."""
+    setattr(p, _SINK_ATTR, (weakref.ref(owner), flat, off, p.numel(), poison))
+
+
+def grad_poison(params):
+    """The poison slot of the optimiser the first registered parameter of `params` belongs to, or None."""
+    for p in params:
+        e = getattr(p, _SINK_ATTR, None)
+        if e is not None and e[0]() is not None:
+            return e[4]
+    return None
 
 
 def clear_grad_sink(p):

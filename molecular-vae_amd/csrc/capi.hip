@@ -6,6 +6,8 @@ int rnn_fwd_impl(const mvae_rnn_fwd_desc* d, hipStream_t st);
 int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st);
 size_t rnn_bwd_workspace_bytes(const mvae_rnn_bwd_desc* d);
 
+thread_local const void* mvae_tls_status = nullptr;
+
 extern "C" {
 
 int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
@@ -76,18 +78,26 @@ int mvae_dropout_keep(uint32_t seed, uint32_t idx, float p) {
   return h >= (uint32_t)((double)p * 4294967296.0) ? 1 : 0;
 }
 
-int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream) {
-  if (d && d->persist_ws && rnn_persist_fwd_supported(d)) return rnn_persist_fwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream);
-  return rnn_fwd_impl(d, (hipStream_t)stream);      // (the row-resident f32 stacks use persist_ws for their layer-concurrent form)
+int mvae_rnn_fwd(const mvae_rnn_fwd_desc* d, void* stream, const void** status_out) {
+  mvae_tls_status = nullptr;
+  const int rc = (d && d->persist_ws && !d->no_spin && rnn_persist_fwd_supported(d))
+                     ? rnn_persist_fwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream)
+                     : rnn_fwd_impl(d, (hipStream_t)stream);      // (the row-resident f32 stacks use persist_ws for their layer-concurrent form)
+  if (status_out) *status_out = rc == MVAE_OK ? mvae_tls_status : nullptr;
+  return rc;
 }
 size_t mvae_rnn_fwd_persist_workspace(const mvae_rnn_fwd_desc* d) {
   if (!d) return 0;
   if (rnn_persist_fwd_supported(d)) return rnn_persist_fwd_workspace_bytes(d->T);
   return rnn_rowres_fwd_pipe_workspace(d);
 }
-int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream) {
-  if (d && d->persist_ws && rnn_persist_bwd_supported(d)) return rnn_persist_bwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream);
-  return rnn_bwd_impl(d, (hipStream_t)stream);
+int mvae_rnn_bwd(const mvae_rnn_bwd_desc* d, void* stream, const void** status_out) {
+  mvae_tls_status = nullptr;
+  const int rc = (d && d->persist_ws && !d->no_spin && rnn_persist_bwd_supported(d))
+                     ? rnn_persist_bwd(d, d->persist_ws, d->persist_ws_bytes, (hipStream_t)stream)
+                     : rnn_bwd_impl(d, (hipStream_t)stream);
+  if (status_out) *status_out = rc == MVAE_OK ? mvae_tls_status : nullptr;
+  return rc;
 }
 size_t mvae_rnn_bwd_persist_workspace(const mvae_rnn_bwd_desc* d) { return (d && rnn_persist_bwd_supported(d)) ? rnn_persist_bwd_workspace_bytes(d->T) : 0; }
 size_t mvae_rnn_bwd_workspace(const mvae_rnn_bwd_desc* d) { return rnn_bwd_workspace_bytes(d); }

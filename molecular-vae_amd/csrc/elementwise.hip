@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g, floa
 }
 __global__ __launch_bounds__(256) void clip_adam_kernel(long n, float* p, const float* g, float* m, float* v, const float* partial, long npartial,
                                                         float grad_scale, float max_norm, float lr, float b1, float b2, float eps,
-                                                        float bc1, float bc2_sqrt, float* norm_out) {
+                                                        float bc1, float bc2_sqrt, float* norm_out, int norm_out_len, float* poison_reset) {
   __shared__ float red[4];
   __shared__ float s_coef;
   // every block re-derives the global norm from the partials in the same fixed order
@@ -905,11 +905,18 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, float* p, const 
     const float norm = sqrtf(a) * grad_scale;
     float coef = 1.f;
     if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); if (coef > 1.f) coef = 1.f; }
-    s_coef = coef * grad_scale;
-    if (blockIdx.x == 0 && norm_out) norm_out[0] = norm;
+    // a norm that is not finite (a poisoned step: mvae_rnn_*_desc.poison, or genuinely diverged gradients): skip the whole update -- every
+    // block takes the same decision from the same partials
+    const bool finite = norm < __builtin_huge_valf() && norm == norm;
+    s_coef = finite ? coef * grad_scale : __builtin_nanf("");
+    if (blockIdx.x == 0) {
+      if (norm_out) { norm_out[0] = norm; if (!finite && norm_out_len >= 2) norm_out[1] += 1.f; }
+      if (poison_reset) *poison_reset = 0.f;           // mvae_sumsq has read it (stream order); ready for the next step
+    }
   }
   __syncthreads();
   const float coef = s_coef;
+  if (!(coef == coef)) return;
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * coef;
@@ -1435,12 +1442,13 @@ int mvae_sumsq(int64_t n, const float* g, float* partial, void* stream) {
   return MVAE_OK;
 }
 int mvae_clip_adam(int64_t n, float* p, const float* g, float* m, float* v, const float* partial, int64_t npartial, float grad_scale,
-                   float max_norm, float lr, float beta1, float beta2, float eps, int step, float* norm_out, void* stream) {
+                   float max_norm, float lr, float beta1, float beta2, float eps, int step, float* norm_out, int norm_out_len, float* poison_reset,
+                   void* stream) {
   if (!p || !g || !m || !v || !partial || n < 1 || npartial < 1 || step < 1) return MVAE_ERR_INVALID;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (long)n, p, g, m, v, partial,
-                     (long)npartial, grad_scale, max_norm, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), norm_out);
+                     (long)npartial, grad_scale, max_norm, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), norm_out, norm_out_len, poison_reset);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

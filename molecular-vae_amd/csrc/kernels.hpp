@@ -1,5 +1,6 @@
 // Internal launcher declarations (host side).  The extern "C" surface is include/mvae.h.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include "../../include/mvae.h"
@@ -27,6 +28,11 @@ int launch_cast_transpose(int dsrc, int ddst, int R, int C, const void* src, lon
 size_t colsum_workspace_bytes(int M, int N);
 int launch_colsum(int M, int N, const float* X, long ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_selu_bwd(long n, float* dy, const float* y, hipStream_t st);
+
+// Where the launches of the current mvae_rnn_fwd / mvae_rnn_bwd call report a bounded spin that ran out (capi.hip clears it before dispatching
+// and hands it to the caller as *status_out): set by every launcher that enqueues a kernel with bounded spins, left alone by the others.
+extern thread_local const void* mvae_tls_status;
+constexpr int MVAE_MAX_DEVICES = 64;
 
 // rnn_persist.hip: weights-resident dataflow LSTM forward (b = 128, 4 x 1024, bf16)
 bool rnn_persist_fwd_supported(const mvae_rnn_fwd_desc* d);

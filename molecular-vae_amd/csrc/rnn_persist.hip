@@ -49,6 +49,7 @@ struct PersistFwdArgs {
   float* cstate[PNL];              // [2][B][H] fp32: the final cell state goes to slot (T - 1) & 1
   uint32_t* flags;                 // [PNL][T][64], zero at launch
   uint32_t* status;                // [4]: error code, block, layer * 65536 + t, which poll
+  float* poison;                   // optional: receives a quiet NaN when the launch gives up (mvae_rnn_fwd_desc.poison)
   uint32_t spin_limit;
   int safe;                        // != 0: every group of stores is drained (vmcnt(0)) right away -- the counted waits then never have a store in
                                    // flight (tests compare this form with the default one bit for bit)
@@ -366,7 +367,7 @@ __device__ __forceinline__ void persist_fwd_body(const PersistFwdArgs& p, char* 
   if (SAVE && ok) save_half(T - 1, 1, sv);
   if (!ok) {                                      // a bounded spin ran out (or somebody else's did): record who, drain
     if (lane == 0) {
-      if (atomicCAS(p.status, 0u, 1u) == 0u) { p.status[1] = blockIdx.x; p.status[2] = (uint32_t)layer; }
+      if (atomicCAS(p.status, 0u, 1u) == 0u) { p.status[1] = blockIdx.x; p.status[2] = (uint32_t)layer; if (p.poison) *p.poison = __builtin_nanf(""); }
     }
     return;
   }
@@ -409,6 +410,14 @@ bool rnn_persist_fwd_supported(const mvae_rnn_fwd_desc* d) {
     if ((d->ldw_hh[l] & 7) || (reinterpret_cast<uintptr_t>(d->w_hh[l]) & 15)) return false;
   }
   if (d->ldh != PH + 64) return false;
+  // the kernel forms 32-bit byte offsets into hs / gates / cs and builds buffer resources of (int) extents: keep the largest per-layer
+  // buffer ([T][B][4H] bf16) under 2 GiB, and every streamed / stored base 16-byte aligned
+  if ((long)d->T * d->B * (4L * PH + 64) * 2 >= (1L << 31)) return false;
+  for (int l = 0; l < PNL; ++l) {
+    if (reinterpret_cast<uintptr_t>(d->hs[l]) & 15) return false;
+    if (l > 0 && (reinterpret_cast<uintptr_t>(d->w_ih[l]) & 15)) return false;
+    if ((d->cs[l] && (reinterpret_cast<uintptr_t>(d->cs[l]) & 15)) || (d->gates[l] && (reinterpret_cast<uintptr_t>(d->gates[l]) & 15))) return false;
+  }
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   return cus == PWG;
@@ -426,6 +435,8 @@ int rnn_persist_fwd(const mvae_rnn_fwd_desc* d, void* ws, size_t ws_bytes, hipSt
   }
   a.add0 = d->add0; a.ldh = d->ldh;
   a.status = reinterpret_cast<uint32_t*>(ws);
+  a.poison = d->poison;
+  mvae_tls_status = ws;
   a.flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + 64);
   a.dbg = nullptr;
 #ifdef MVAE_TUNING
@@ -437,11 +448,14 @@ int rnn_persist_fwd(const mvae_rnn_fwd_desc* d, void* ws, size_t ws_bytes, hipSt
   a.spin_limit = sp ? (uint32_t)atoi(sp) : (1u << 20);
   const char* sf = mvae_knob("MVAE_PERSIST_SAFE");
   a.safe = (sf && atoi(sf) != 0) ? 1 : 0;
-  static bool attr = false;
-  if (!attr) {
+  // the 160 KB dynamic-LDS opt-in is a per-DEVICE function attribute: once per device, not once per process
+  static std::atomic<bool> attr[MVAE_MAX_DEVICES];
+  int dev_id = 0;
+  MVAE_CHECK_HIP(hipGetDevice(&dev_id));
+  if (dev_id < 0 || dev_id >= MVAE_MAX_DEVICES || !attr[dev_id].load(std::memory_order_acquire)) {
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS));
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS));
-    attr = true;
+    if (dev_id >= 0 && dev_id < MVAE_MAX_DEVICES) attr[dev_id].store(true, std::memory_order_release);
   }
   bool save = true;
   for (int l = 0; l < PNL; ++l) if (!d->gates[l] || !d->cs[l]) save = false;

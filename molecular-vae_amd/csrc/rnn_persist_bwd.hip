@@ -49,6 +49,7 @@ struct PersistBwdArgs {
   float* exch;                     // EXCH_BYTES
   uint32_t* dflags;                // [PNL][T][64]: the dG^l_t tile of workgroup j is in memory
   uint32_t* status;
+  float* poison;                   // optional: receives a quiet NaN when the launch gives up (mvae_rnn_bwd_desc.poison)
   uint32_t spin_limit;
   int safe;
   unsigned long long* dbg;
@@ -412,7 +413,7 @@ __device__ __forceinline__ void persist_bwd_body(const PersistBwdArgs& p, char* 
   }
   if (!ok) {
     if (lane == 0) {
-      if (atomicCAS(p.status, 0u, 1u) == 0u) { p.status[1] = blockIdx.x; p.status[2] = (uint32_t)layer; }
+      if (atomicCAS(p.status, 0u, 1u) == 0u) { p.status[1] = blockIdx.x; p.status[2] = (uint32_t)layer; if (p.poison) *p.poison = __builtin_nanf(""); }
     }
   }
 }
@@ -447,7 +448,9 @@ bool rnn_persist_bwd_supported(const mvae_rnn_bwd_desc* d) {
     if (d->dh_last[l] || d->dh0[l] || !d->w_hhT[l] || !d->cs[l] || !d->gates[l] || !d->dG[l]) return false;
     if ((d->ldw_hhT[l] & 7) || (reinterpret_cast<uintptr_t>(d->w_hhT[l]) & 15) || (reinterpret_cast<uintptr_t>(d->dG[l]) & 15)) return false;
     if (l > 0 && (!d->w_ihT[l] || (d->ldw_ihT[l] & 7) || (reinterpret_cast<uintptr_t>(d->w_ihT[l]) & 15))) return false;
+    if ((reinterpret_cast<uintptr_t>(d->gates[l]) & 15) || (reinterpret_cast<uintptr_t>(d->cs[l]) & 15)) return false;
   }
+  if ((long)d->T * d->B * (long)LDG * 2 >= (1L << 31)) return false;      // 32-bit byte offsets / (int) buffer-resource extents in the kernel
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   return cus == PWG;
@@ -468,6 +471,8 @@ int rnn_persist_bwd(const mvae_rnn_bwd_desc* d, void* ws, size_t ws_bytes, hipSt
   head = (head + 4095) & ~(size_t)4095;
   char* w = reinterpret_cast<char*>(ws);
   a.status = reinterpret_cast<uint32_t*>(w);
+  a.poison = d->poison;
+  mvae_tls_status = ws;
   a.dflags = reinterpret_cast<uint32_t*>(w + 64);
   a.exch = reinterpret_cast<float*>(w + head);
   a.dbg = nullptr;
@@ -478,10 +483,12 @@ int rnn_persist_bwd(const mvae_rnn_bwd_desc* d, void* ws, size_t ws_bytes, hipSt
   a.spin_limit = sp ? (uint32_t)atoi(sp) : (1u << 20);
   const char* sf = mvae_knob("MVAE_PERSIST_SAFE");
   a.safe = (sf && atoi(sf) != 0) ? 1 : 0;
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<bool> attr[MVAE_MAX_DEVICES];       // per-device function attribute
+  int dev_id = 0;
+  MVAE_CHECK_HIP(hipGetDevice(&dev_id));
+  if (dev_id < 0 || dev_id >= MVAE_MAX_DEVICES || !attr[dev_id].load(std::memory_order_acquire)) {
     MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS));
-    attr = true;
+    if (dev_id >= 0 && dev_id < MVAE_MAX_DEVICES) attr[dev_id].store(true, std::memory_order_release);
   }
   for (int r0 = 0; r0 < d->B; r0 += PB) {
     a.row0 = r0;

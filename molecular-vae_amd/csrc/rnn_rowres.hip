@@ -67,7 +67,7 @@ constexpr int RR_TBL_ROWS = 64, RR_TBL_T = 256;      // LDS table / id capacity 
 // Pipeline context of the layer-concurrent forms: `above` = progress word of the workgroup that produces our input (same batch rows, the
 // neighbouring layer; nullptr: the input is complete), `mine` = our own progress word (nullptr: nobody consumes our output inside the launch).
 // Forward: progress = number of completed time steps; hs[t] is visible once progress >= t + 1.
-struct RowPipe { const uint32_t* above; uint32_t* mine; uint32_t* status; uint32_t spin_limit; };
+struct RowPipe { const uint32_t* above; uint32_t* mine; uint32_t* status; uint32_t spin_limit; float* poison; };
 
 template <int H, bool HASX, int NTHR, bool TBL = false, bool PIPE = false>
 __device__ __forceinline__ void lstm_rowres_fwd_body(const RowResF& p, int rowgroup, RowPipe pp) {
@@ -90,7 +90,7 @@ __device__ __forceinline__ void lstm_rowres_fwd_body(const RowResF& p, int rowgr
       if (known >= need) return;
       __builtin_amdgcn_s_sleep(4);
     }
-    if (pp.status) atomicCAS(pp.status, 0u, 3u);
+    if (pp.status && atomicCAS(pp.status, 0u, 3u) == 0u && pp.poison) *pp.poison = __builtin_nanf("");
     known = 0xffffffffu;
   };
   auto load_x = [&](const float* src) -> float4 {  // the layer below's h: agent-scope loads in the pipelined form (not through this CU's L1)
@@ -240,13 +240,13 @@ __global__ __launch_bounds__(NTHR) void lstm_rowres_fwd_kernel(RowResF p) {
 // uses this form only when every workgroup of the grid is resident at once.
 struct RowResFAll { RowResF l[MVAE_MAX_LAYERS]; int nl; };
 template <int H, bool TBL0>
-__global__ __launch_bounds__(320) void lstm_rowres_fwd_pipe_kernel(RowResFAll a, uint32_t* flags, uint32_t* status, uint32_t spin_limit) {
+__global__ __launch_bounds__(320) void lstm_rowres_fwd_pipe_kernel(RowResFAll a, uint32_t* flags, uint32_t* status, uint32_t spin_limit, float* poison) {
   const int nblk = gridDim.x / a.nl;
   const int l = (int)(blockIdx.x / nblk), g = (int)(blockIdx.x % nblk);
   RowPipe pp;
   pp.above = (l > 0) ? flags + (l - 1) * nblk + g : nullptr;
   pp.mine = (l + 1 < a.nl) ? flags + l * nblk + g : nullptr;
-  pp.status = status; pp.spin_limit = spin_limit;
+  pp.status = status; pp.spin_limit = spin_limit; pp.poison = poison;
   if (l == 0) lstm_rowres_fwd_body<H, false, 320, TBL0, true>(a.l[0], g, pp);
   else lstm_rowres_fwd_body<H, true, 320, false, true>(a.l[l], g, pp);
 }
@@ -291,7 +291,7 @@ __device__ __forceinline__ void rowres_bwd_layer(const RowResB& p, float (&gbuf)
       if (known >= need) return;
       __builtin_amdgcn_s_sleep(4);
     }
-    if (pp.status) atomicCAS(pp.status, 0u, 2u);          // gave up: the results are invalid, the launch still ends
+    if (pp.status && atomicCAS(pp.status, 0u, 2u) == 0u && pp.poison) *pp.poison = __builtin_nanf("");          // gave up: the results are invalid, the launch still ends
     known = 0xffffffffu;
   };
   float W[NG][KW];
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_all_kernel(RowResBAll a) 
 // after the other: the pass takes ~T + 2 (layers - 1) steps instead of layers x T.  The top layer comes first in the grid (dispatch order is
 // not promised: the launcher only uses this form when EVERY workgroup of the grid is resident at once, so nobody waits for a queued one).
 template <int H>
-__global__ __launch_bounds__(256) void lstm_rowres_bwd_pipe_kernel(RowResBAll a, uint32_t* flags, uint32_t* status, uint32_t spin_limit) {
+__global__ __launch_bounds__(256) void lstm_rowres_bwd_pipe_kernel(RowResBAll a, uint32_t* flags, uint32_t* status, uint32_t spin_limit, float* poison) {
   __shared__ float gbuf[RR_ROWS][4 * H + 24];
   __shared__ float red[4][RR_ROWS][192];
   const int nblk = gridDim.x / a.nl;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void lstm_rowres_bwd_pipe_kernel(RowResBAll a,
   RowPipe pp;
   pp.above = (l + 1 < a.nl) ? flags + (l + 1) * nblk + g : nullptr;
   pp.mine = (l > 0) ? flags + l * nblk + g : nullptr;
-  pp.status = status; pp.spin_limit = spin_limit;
+  pp.status = status; pp.spin_limit = spin_limit; pp.poison = poison;
   if (l > 0) rowres_bwd_layer<H, 256, true, true>(a.l[l], gbuf, red, g, pp);
   else rowres_bwd_layer<H, 256, false, true>(a.l[l], gbuf, red, g, pp);
 }
@@ -846,7 +846,7 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
     const int nblk = (B + RR_ROWS - 1) / RR_ROWS, NL = d->layers;
     int dev = 0, cus = 0;
     const char* pk = mvae_knob("MVAE_ROWRES_PIPE");
-    bool pipe = (pk ? atoi(pk) != 0 : true) && NL >= 2 && d->persist_ws && d->persist_ws_bytes >= ((size_t)NL * nblk + 16) * sizeof(uint32_t);
+    bool pipe = (pk ? atoi(pk) != 0 : true) && !d->no_spin && NL >= 2 && d->persist_ws && d->persist_ws_bytes >= ((size_t)NL * nblk + 16) * sizeof(uint32_t);
     if (pipe && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || NL * nblk > cus)) pipe = false;
     for (int l = 1; l < NL && pipe; ++l) if (reinterpret_cast<uintptr_t>(d->hs[l - 1]) & 15) pipe = false;
     if (pipe) {
@@ -867,8 +867,11 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       uint32_t* status = reinterpret_cast<uint32_t*>(d->persist_ws);       // [status 16 words | progress words]: the host reads the first 16 bytes
       uint32_t* flags = status + 16;
       MVAE_CHECK_HIP(hipMemsetAsync(status, 0, ((size_t)NL * nblk + 16) * sizeof(uint32_t), st));
-      if (tbl) hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, true>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, 1u << 20);
-      else hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, false>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, 1u << 20);
+      const char* sp = mvae_knob("MVAE_ROWRES_SPIN");          // tests: 1 = give up at the first hand-off that is not there yet
+      const uint32_t spin = sp ? (uint32_t)atoi(sp) : (1u << 20);
+      if (tbl) hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, true>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, spin, d->poison);
+      else hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, false>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, spin, d->poison);
+      mvae_tls_status = status;
       MVAE_CHECK_HIP(hipGetLastError());
       return MVAE_OK;
     }
@@ -938,13 +941,15 @@ int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   const int nblk = (B + RR_ROWS - 1) / RR_ROWS;
   int dev = 0, cus = 0;
   const char* pk = mvae_knob("MVAE_ROWRES_PIPE");
-  bool pipe = (pk ? atoi(pk) != 0 : true) && NL >= 2 && NL <= 3;
+  bool pipe = (pk ? atoi(pk) != 0 : true) && !d->no_spin && NL >= 2 && NL <= 3;
   if (pipe && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || NL * nblk > cus)) pipe = false;
   uint32_t* flags = need ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d->split_ws) + (size_t)2 * T * B * H * sizeof(float)) : nullptr;
   uint32_t* status = flags ? flags + (size_t)NL * nblk : nullptr;
-  if (flags) MVAE_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)NL * nblk + 16) * sizeof(uint32_t), st));     // progress words + status (the host reads the status in either form)
   if (pipe && flags) {
-    hipLaunchKernelGGL((lstm_rowres_bwd_pipe_kernel<H>), dim3(NL * nblk), dim3(256), 0, st, all, flags, status, 1u << 20);
+    MVAE_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)NL * nblk + 16) * sizeof(uint32_t), st));     // progress words + status
+    const char* sp = mvae_knob("MVAE_ROWRES_SPIN");
+    hipLaunchKernelGGL((lstm_rowres_bwd_pipe_kernel<H>), dim3(NL * nblk), dim3(256), 0, st, all, flags, status, sp ? (uint32_t)atoi(sp) : (1u << 20), d->poison);
+    mvae_tls_status = status;              // (the layer-by-layer form has no spins: no status to report, no memset)
   } else {
     hipLaunchKernelGGL((lstm_rowres_bwd_all_kernel<H>), dim3(nblk), dim3(256), 0, st, all);
   }

@@ -413,6 +413,8 @@ class MolEncoder(nn.Module, _SavedState):
         if eps is None and not (self.lmbd.noise == "device" and x.is_cuda):
             eps = self.lmbd.draw_eps(B, o, x.device)
         params = list(self.parameters())
+        # a training forward under FusedAdam: launches with bounded spins report a failure into the optimiser's poison slot (ops.PERSIST_DEFAULT)
+        self.__dict__["_poison"] = L.grad_poison(params) if torch.is_grad_enabled() else None
         z, mu, logv = _EncoderFn.apply(self, x, eps, *params)        # eps None: drawn inside mvae_lambda_fwd from lmbd.noise_stream
         self.lmbd.mu, self.lmbd.log_v = mu, logv
         return z, mu, logv
@@ -517,7 +519,8 @@ class _EncoderFn(torch.autograd.Function):
         gates = [ws.get(f"gates{l}", (Lq, B, G4), f32, dev) for l in range(NL)]
         cstate = [ws.get(f"cstate{l}", (2, B, H), f32, dev) for l in range(NL)]
         ops.rnn_fwd(L.CELL_LSTM, f32, Lq, B, H, None, 0, P["Wih"], [Hp] * NL, P["Whh"], [Hp] * NL, [None] + P["bias"][1:],
-                    hs, Hp, cs, gates, cstate, zero_padded_k=True, tag="enc_lstm_fwd", add_table=tbl, add_index=idx)
+                    hs, Hp, cs, gates, cstate, zero_padded_k=True, tag="enc_lstm_fwd", add_table=tbl, add_index=idx,
+                    poison=mod.__dict__.get("_poison"))
         # K3: conv stack over the hidden axis, sequence position = channel (models.py:129-131)
         c1, c2, c3 = mod.conv_1[0], mod.conv_2[0], mod.conv_3[0]
         k = c1.kernel_size
@@ -633,7 +636,7 @@ class _EncoderFn(torch.autograd.Function):
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         fork.run_deferred(1)      # the decoder's remaining weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
         ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, Hp, cs, gates,
-                    dG, dstate, tag="enc_lstm_bwd")
+                    dG, dstate, tag="enc_lstm_bwd", poison=L.grad_poison(params))
         _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp)
         # K1 backward: table gradient, then embedding / W_ih0
         dtbl = W("dtbl", (Cv, G4))
@@ -755,7 +758,7 @@ class _DecoderFn(torch.autograd.Function):
         gates = [None if infer else ws.get(f"gates{l}", (Lq, B, G4), dt, dev) for l in range(NL)]
         cstate = [ws.get(f"cstate{l}", (2, B, H), f32, dev) for l in range(NL)]
         ops.rnn_fwd(L.CELL_LSTM, dt, Lq, B, H, gx0, 0, P["Wih"], [P["ldw"]] * NL, P["Whh"], [P["ldw"]] * NL, [None] + P["bias"][1:],
-                    hs, ldh, cs, gates, cstate, tag="dec_lstm_fwd")
+                    hs, ldh, cs, gates, cstate, tag="dec_lstm_fwd", poison=(None if infer else L.grad_poison(params)))
         # K8: output head + softmax over the class axis
         logits = ws.get("logits", (TB, Cv), f32, dev)
         ops.gemm_nt(hs[-1].view(TB, ldh), P["Wout"], logits, TB, Cv, H, bias=om.bias)
@@ -822,7 +825,7 @@ class _DecoderFn(torch.autograd.Function):
         dstate = [W(f"dstate{l}", (2, B, H)) for l in range(NL)]
         ops.rnn_bwd(L.CELL_LSTM, dt, Lq, B, H, P["WhhT"], [P["ldwT"]] * NL, P["WihT"], [P["ldwT"]] * NL, dy, H, hs, ldh, cs, gates,
                     dG, dstate, ldg=ldg, tag="dec_lstm_bwd", dy_a=(dl if fuse_dy else None), dy_w=(P["WoutT"] if fuse_dy else None),
-                    dy_k=(_dyk(Cv) if fuse_dy else 0))
+                    dy_k=(_dyk(Cv) if fuse_dy else 0), poison=L.grad_poison(params))
 
         # Everything that only produces parameter gradients (nothing on the path to dz) -- the output head + the LSTM weights -- is cut into
         # PARTS, each a set of layers whose gradients are one contiguous range of the flat gradient buffer, produced (and, in DP, all-reduced)

@@ -503,7 +503,10 @@ class NoiseStream:
 
     def _default_seed(self):
         import torch.distributed as dist
-        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        try:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        except (ValueError, RuntimeError):        # no default process group after all
+            rank = 0
         NoiseStream._instances[0] += 1
         words = (C.c_uint32 * 2)()
         L.load().mvae_normal_words(torch.initial_seed() & 0xFFFFFFFF, (rank << 20) + NoiseStream._instances[0], words)
@@ -569,19 +572,42 @@ def dropout_keep_mask(seed, shape_lt_b_h, p):
     return (h >= thresh).astype(np.uint8).reshape(shape_lt_b_h)
 
 
-# The weights-resident dataflow schedule of mvae_rnn_fwd (rnn_persist.hip; the per-rank shape of the 8-GPU configuration: LSTM 4 x 1024, b = 128,
-# bf16).  PERSIST_DEFAULT: used whenever the library serves the shape ("1") or never ("0"); `rnn_fwd(persist=...)` / MVAE_PERSIST (under
-# MVAE_TUNING=1) override it.  The launch cannot hang -- its spins are bounded -- but it can FAIL (a workgroup not resident because something
-# else held a CU): it then leaves a status record, which is copied to pinned host memory behind the launch and checked at the next call
-# and by persist_check().
+# Schedules with BOUNDED SPINS: the weights-resident dataflow passes of the decoder LSTM (rnn_persist*.hip; the per-rank shape of the 8-GPU
+# configuration: 4 x 1024, b = 128 / 256, bf16) and the layer-concurrent row-resident encoder passes (rnn_rowres.hip).  Such a launch cannot hang,
+# but it can GIVE UP (a workgroup not resident because something else held a compute unit): it then leaves a status record -- the library says
+# where (status_out of mvae_rnn_fwd / mvae_rnn_bwd) -- and, when the caller passed a `poison` slot, a NaN there.  Two ways to survive that:
+#   * poison given (a training step under FusedAdam): nothing waits.  The NaN sits in the spare slot behind the flat gradient buffer, so the
+#     optimiser kernel skips the whole update of that step on the device (in data parallel the slot is all-reduced with the gradient: every rank
+#     skips together); the status record is copied to pinned memory behind the launch and looked at later (persist_check).
+#   * no poison (evaluation, plain torch optimisers): the call waits for its status record and, on a failure, runs the pass again on the
+#     schedule without spins -- same buffers, every one of them is written as a whole by either schedule.
+# Either way the failure is counted and reported once (warning); after PERSIST_MAX_FAILURES of them the spinning schedules are switched off
+# for the rest of the process (`no_spin` in the descriptors).  PERSIST_DEFAULT: "1" = use them wherever the library serves the shape.
 PERSIST_DEFAULT = "1"
-PERSIST_STATS = {"launches": 0, "rowres_pipe": 0, "bwd_launches": 0}     # passes that took the persistent decoder schedule / the layer-concurrent encoder form (tests / logs)
+PERSIST_MAX_FAILURES = 3
+PERSIST_STATS = {"launches": 0, "rowres_pipe": 0, "bwd_launches": 0, "failures": 0, "reruns": 0, "disabled": False}     # passes that took a spinning schedule; what went wrong (tests / logs / bench line)
 _PERSIST_PENDING = []      # [(pinned int32[4], event, what)]
+_PERSIST_WARNED = [False]
+
+
+def _spin_failure(what, rec):
+    PERSIST_STATS["failures"] += 1
+    if PERSIST_STATS["failures"] >= PERSIST_MAX_FAILURES and not PERSIST_STATS["disabled"]:
+        PERSIST_STATS["disabled"] = True
+    if not _PERSIST_WARNED[0] or PERSIST_STATS["disabled"]:
+        import warnings
+        warnings.warn(f"mvae: {what}: a launch with bounded spins gave up waiting for a hand-off (status {list(rec)}: code, block, layer) -- not "
+                      "all of its workgroups were resident (another kernel held compute units).  Its outputs were discarded (training: the "
+                      "optimiser skipped that step on the device; otherwise the pass was run again on the schedule without spins)."
+                      + (f"  {PERSIST_STATS['failures']} such failures: these schedules are now off for this process." if PERSIST_STATS["disabled"] else ""),
+                      RuntimeWarning, stacklevel=3)
+        _PERSIST_WARNED[0] = True
 
 
 def persist_check(sync=False):
-    """Raise MvaeError if a persistent launch whose status has arrived (sync: wait for all of them) reported a failed hand-off."""
-    keep = []
+    """Look at the status records that have arrived (sync: wait for all of them); a failed hand-off is counted and warned about (see above) --
+    nothing is raised: the device has already kept the garbage out of the weights.  Returns the number of failures found by this call."""
+    keep, found = [], 0
     for host, ev, what in _PERSIST_PENDING:
         if sync:
             ev.synchronize()
@@ -589,18 +615,47 @@ def persist_check(sync=False):
             keep.append((host, ev, what))
             continue
         if int(host[0]) != 0:
-            _PERSIST_PENDING.clear()
-            raise L.MvaeError(f"{what}: the persistent dataflow launch gave up waiting for a hand-off (status {host.tolist()}: code, block, layer) "
-                              "-- its outputs are invalid.  Not all 256 workgroups were resident (another kernel held compute units); "
-                              "run the step without concurrent work or disable the schedule (ops.PERSIST_DEFAULT = '0')")
+            found += 1
+            _spin_failure(what, host.tolist())
     _PERSIST_PENDING[:] = keep
+    return found
+
+
+def _status_view(addr, bufs):
+    """int32[4] view of the status record at device address `addr`, which lies inside one of the scratch tensors `bufs`."""
+    for b in bufs:
+        if b is not None and b.data_ptr() <= addr and addr + 16 <= b.data_ptr() + b.numel() * b.element_size():
+            off = addr - b.data_ptr()
+            return b.view(torch.uint8)[off:off + 16].view(torch.int32)
+    raise L.MvaeError("mvae_rnn_*: the status record the library reported lies outside the scratch buffers of the call")
+
+
+def _after_spin_launch(what, addr, bufs, poison, rerun):
+    """A launch with bounded spins was enqueued; its status record is at `addr`.  poison given: asynchronous bookkeeping only.  Otherwise wait
+    for the record and run `rerun()` (the same pass with no_spin set) if the launch gave up."""
+    rec = _status_view(addr, bufs)
+    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+    host.copy_(rec, non_blocking=True)
+    ev = torch.cuda.Event(); ev.record()
+    if poison is not None:
+        _PERSIST_PENDING.append((host, ev, what))
+        if len(_PERSIST_PENDING) > 64:
+            persist_check()
+        return
+    ev.synchronize()
+    if int(host[0]) != 0:
+        _spin_failure(what, host.tolist())
+        PERSIST_STATS["reruns"] += 1
+        rerun()
 
 
 def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh, bias, hs, ldh, cs, gates, cstate,
             x0=None, x0_ld=0, in0=0, h0=None, ldh0=0, lengths=None, zero_padded_k=False, tag=None,
-            hdrop=None, drop_mask=None, drop_p=0.0, drop_seed=0, add_table=None, add_index=None, persist=None):
+            hdrop=None, drop_mask=None, drop_p=0.0, drop_seed=0, add_table=None, add_index=None, persist=None, poison=None):
     """add_table [rows, G*H] fp32 + add_index [B, L >= T] int64: layer 0 adds table row add_index[b, t] in its epilogue (no gathered copy).
-    persist: True / False / None (= PERSIST_DEFAULT): the weights-resident dataflow schedule where the library serves the shape."""
+    persist: True / False / None (= PERSIST_DEFAULT): the schedules with bounded spins (weights-resident dataflow pass / layer-concurrent
+    row-resident pass) where the library serves the shape.  poison: the optimiser's poison slot (see the note above PERSIST_DEFAULT); None:
+    the call verifies such a launch itself and re-runs the pass on a failure."""
     d = L.RnnFwdDesc()
     NL = len(w_hh)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H, d.in0 = cell, dt_code(dtype), NL, T, B, H, in0
@@ -634,7 +689,7 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
         if drop_mask is not None:
             _fill(d.drop_mask, drop_mask)
         d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
-    use_p = (L.knob("MVAE_PERSIST", PERSIST_DEFAULT) != "0") if persist is None else bool(persist)
+    use_p = ((L.knob("MVAE_PERSIST", PERSIST_DEFAULT) != "0") if persist is None else bool(persist)) and not PERSIST_STATS["disabled"]
     pws = None
     if use_p:
         persist_check()
@@ -644,21 +699,25 @@ def rnn_fwd(cell, dtype, T, B, H, add0, add0_tstride, w_ih, ldw_ih, w_hh, ldw_hh
             d.persist_ws, d.persist_ws_bytes = pws.data_ptr(), need
         elif persist:
             raise L.MvaeError("rnn_fwd(persist=True): this shape / device is not served by the persistent schedule")
+    d.no_spin = 0 if use_p else 1
+    d.poison = poison.data_ptr() if poison is not None else None
+    status = C.c_void_p()
     with _Timed(tag):
-        check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr()), "mvae_rnn_fwd")
-    if pws is not None:
+        check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr(), C.byref(status)), "mvae_rnn_fwd")
+    if status.value:                 # the library took a schedule with bounded spins and says where its status record is
         PERSIST_STATS["launches" if dtype == torch.bfloat16 else "rowres_pipe"] += 1
-        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-        host.copy_(pws[:16].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event(); ev.record()
-        _PERSIST_PENDING.append((host, ev, tag or "mvae_rnn_fwd"))
+
+        def rerun():
+            d.no_spin, d.poison = 1, None
+            check(L.load().mvae_rnn_fwd(C.byref(d), stream_ptr(), None), "mvae_rnn_fwd (again, without spins)")
+        _after_spin_launch(tag or "mvae_rnn_fwd", status.value, (pws,), poison, rerun)
 
 
 def rnn_bwd_persist_wanted(cell, dtype, NL, B, H, ldg, device):
     """Would rnn_bwd take the weights-resident dataflow schedule for this shape if it is given the output gradient as `dy`?  (The library has
     the last word -- mvae_rnn_bwd_persist_workspace -- this only lets the caller choose the gradient's form; a wrong guess costs speed, not
     correctness.)"""
-    if L.knob("MVAE_PERSIST_BWD", PERSIST_DEFAULT) == "0":
+    if L.knob("MVAE_PERSIST_BWD", PERSIST_DEFAULT) == "0" or PERSIST_STATS["disabled"]:
         return False
     if cell != L.CELL_LSTM or dtype != torch.bfloat16 or NL != 4 or H != 1024 or B not in (128, 256) or ldg != 4 * H + 64:
         return False
@@ -667,11 +726,12 @@ def rnn_bwd_persist_wanted(cell, dtype, NL, B, H, ldg, device):
 
 def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs, ldh, cs, gates, dG, dstate,
             ldg=None, h0=None, ldh0=0, lengths=None, dh_last=None, dGh=None, dh0=None, tag=None,
-            drop_mask=None, drop_p=0.0, drop_seed=0, dy_a=None, dy_w=None, dy_k=0, persist=None):
+            drop_mask=None, drop_p=0.0, drop_seed=0, dy_a=None, dy_w=None, dy_k=0, persist=None, poison=None):
     """dy_a [T*B, ld] / dy_w [H, ld] (dtype, zero-padded to dy_k columns): the output gradient as a product dy = dy_a . dy_w^T, contracted
     by the top layer's cell itself (no [T, B, H] fp32 dy tensor).
     persist: True / False / None (= PERSIST_DEFAULT): the weights-resident dataflow backward where the library serves the shape (it wants the
-    output gradient as `dy`, see rnn_bwd_persist_served)."""
+    output gradient as `dy`, see rnn_bwd_persist_served), and the layer-concurrent row-resident form of the narrow f32 stacks.  poison: as in
+    rnn_fwd."""
     d = L.RnnBwdDesc()
     NL = len(w_hhT)
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = cell, dt_code(dtype), NL, T, B, H
@@ -706,7 +766,7 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
     need = L.load().mvae_rnn_bwd_workspace(C.byref(d))     # scratch of the split-K schedules (used only when the shape qualifies)
     sws = Scratch.get(need, dy.device if dy is not None else dG[0].device, tag="rnn_split")
     d.split_ws, d.split_ws_bytes = sws.data_ptr(), need
-    use_p = (L.knob("MVAE_PERSIST_BWD", PERSIST_DEFAULT) != "0") if persist is None else bool(persist)
+    use_p = ((L.knob("MVAE_PERSIST_BWD", PERSIST_DEFAULT) != "0") if persist is None else bool(persist)) and not PERSIST_STATS["disabled"]
     pws = None
     if use_p:
         pneed = L.load().mvae_rnn_bwd_persist_workspace(C.byref(d))
@@ -716,32 +776,30 @@ def rnn_bwd(cell, dtype, T, B, H, w_hhT, ldw_hhT, w_ihT, ldw_ihT, dy, dy_ld, hs,
             d.persist_ws, d.persist_ws_bytes = pws.data_ptr(), pneed
         elif persist:
             raise L.MvaeError("rnn_bwd(persist=True): this shape / device / gradient form is not served by the persistent schedule")
+    d.no_spin = 0 if use_p else 1
+    d.poison = poison.data_ptr() if poison is not None else None
+    status = C.c_void_p()
     with _Timed(tag):
-        check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr()), "mvae_rnn_bwd")
-    if pws is not None:
-        PERSIST_STATS["bwd_launches"] += 1
-        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-        host.copy_(pws[:16].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event(); ev.record()
-        _PERSIST_PENDING.append((host, ev, tag or "mvae_rnn_bwd"))
-        return
-    if cell == L.CELL_LSTM and dtype == torch.float32 and H == 72 and 2 <= NL <= 3 and need:
-        # the layer-concurrent row-resident backward (rnn_rowres.hip) polls progress words with BOUNDED spins; its status word sits behind
-        # them in the workspace: [2 x T x B x H fp32 | NL x ceil(B / 4) words | status] -- checked like the persistent forward's
-        off = 2 * T * B * H * 4 + NL * ((B + 3) // 4) * 4
-        if off + 16 <= need:
-            persist_check()
-            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-            host.copy_(sws[off:off + 16].view(torch.int32), non_blocking=True)
-            ev = torch.cuda.Event(); ev.record()
-            _PERSIST_PENDING.append((host, ev, tag or "mvae_rnn_bwd (row-resident, layer-concurrent)"))
+        check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr(), C.byref(status)), "mvae_rnn_bwd")
+    if status.value:                 # which schedule ran is the library's knowledge: it reports the status record of a launch with bounded spins
+        if pws is not None and pws.data_ptr() <= status.value < pws.data_ptr() + pws.numel():
+            PERSIST_STATS["bwd_launches"] += 1
+        else:
+            PERSIST_STATS["rowres_pipe"] += 1
+
+        def rerun():
+            d.no_spin, d.poison = 1, None
+            check(L.load().mvae_rnn_bwd(C.byref(d), stream_ptr(), None), "mvae_rnn_bwd (again, without spins)")
+        _after_spin_launch(tag or "mvae_rnn_bwd", status.value, (pws, sws), poison, rerun)
 
 
 def sumsq(g, partial):
     check(L.load().mvae_sumsq(g.numel(), ptr(g), ptr(partial), stream_ptr()), "mvae_sumsq")
 
 
-def clip_adam(p, g, m, v, partial, grad_scale, max_norm, lr, b1, b2, eps, step, norm_out):
+def clip_adam(p, g, m, v, partial, grad_scale, max_norm, lr, b1, b2, eps, step, norm_out, poison_reset=None):
+    """norm_out [>= 1]: [0] = the pre-clip norm; [1] (when present) counts the steps the kernel skipped because the norm was not finite.
+    poison_reset: the poison slot, set back to zero by the launch."""
     check(L.load().mvae_clip_adam(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(partial), partial.numel(), float(grad_scale),
-                                  float(max_norm), float(lr), float(b1), float(b2), float(eps), int(step), ptr(norm_out),
-                                  stream_ptr()), "mvae_clip_adam")
+                                  float(max_norm), float(lr), float(b1), float(b2), float(eps), int(step), ptr(norm_out), norm_out.numel(),
+                                  ptr(poison_reset), stream_ptr()), "mvae_clip_adam")

@@ -195,9 +195,13 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             dev = ps[0].device
             n = sum(p.numel() for p in ps)
+            # One spare element behind the parameters in all four flat buffers: the POISON slot.  A persistent launch that gives up stores a
+            # NaN into g[n] (mvae_rnn_*_desc.poison); mvae_sumsq covers the slot, so the norm becomes NaN and mvae_clip_adam skips the whole
+            # update -- in data parallel on EVERY rank, because the slot travels with the last gradient bucket of the all-reduce (sharded
+            # form: with the all-reduced partial sums).  It is zero otherwise (p[n], m[n], v[n] never leave zero) and adds nothing to the norm.
             # sharded form: equal slices whose boundaries fall on the 64K-element chunks of the gradient-norm partial sums (zero padding)
             chunk = 1 << 16
-            shard_elems = ((n + world * chunk - 1) // (world * chunk)) * chunk if self.shard else n
+            shard_elems = ((n + 1 + world * chunk - 1) // (world * chunk)) * chunk if self.shard else n + 1
             n_alloc = shard_elems * world
             pflat = torch.zeros(n_alloc, dtype=torch.float32, device=dev)
             m = torch.zeros_like(pflat); v = torch.zeros_like(pflat); g = torch.zeros_like(pflat)
@@ -212,17 +216,23 @@ class FusedAdam(torch.optim.Optimizer):
                 off += k
             nparts = (n_alloc + (1 << 16) - 1) >> 16
             self._flat.append(dict(params=ps, p=pflat, m=m, v=v, g=g, partial=torch.zeros(nparts, device=dev),
-                                   norm=torch.zeros(1, device=dev), step=0, n=n, shard_elems=shard_elems))
+                                   norm=torch.zeros(2, device=dev), step=0, n=n, shard_elems=shard_elems, poison=g[n:n + 1]))
             off = 0
             for p in ps:                 # modules may write their gradients straight into g (see _lib.register_grad_sink)
-                L.register_grad_sink(p, self, g, off)
+                L.register_grad_sink(p, self, g, off, poison=g[n:n + 1])
                 off += p.numel()
         L.PARAM_EPOCH[0] += 1
 
     @property
     def last_grad_norm(self):
         """Device tensor holding the pre-clip global gradient norm of the last step (train.py:102's return value)."""
-        return self._flat[0]["norm"]
+        return self._flat[0]["norm"][:1]
+
+    @property
+    def skipped_steps(self):
+        """Device tensor: how many step() calls the optimiser kernel turned into no-ops because the global gradient norm was not finite (a
+        persistent launch gave up and poisoned the step, or the gradients diverged).  Reading it synchronises; nothing in step() does."""
+        return self._flat[0]["norm"][1:2]
 
     def gather_grads(self):
         """Copy every ``p.grad`` into the flat gradient buffer (missing grads count as zero); returns the flats."""
@@ -253,7 +263,9 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        ops.persist_check()            # a persistent dataflow launch of this step's forward that gave up leaves a status record: raise, never train on garbage
+        # A launch with bounded spins that gave up during this step has poisoned the gradient buffer's spare slot ON THE DEVICE: the kernels below
+        # then skip the update by themselves, on every rank -- no host wait here.  persist_check only reports what has already arrived.
+        ops.persist_check()
         ops.join_pending()             # gradients produced on a side stream (decoder weight-gradient GEMMs)
         flats = self.gather_grads()
         sync = self.grad_sync
@@ -283,7 +295,7 @@ class FusedAdam(torch.optim.Optimizer):
                     ops.sumsq(gs, f["partial"][r * cps:(r + 1) * cps])
                     dist.all_reduce(f["partial"], group=sync.group)    # disjoint slices + zeros: a gather, a few KB; same values on every rank
                     ops.clip_adam(f["p"][sl], gs, f["m"][sl], f["v"][sl], f["partial"], scale, group["max_grad_norm"], group["lr"], b1, b2,
-                                  group["eps"], f["step"], f["norm"])
+                                  group["eps"], f["step"], f["norm"], poison_reset=f["poison"])
                 with ops._Timed("dp_allreduce_exposed"):
                     sync.all_gather(f["p"], S)
                 self._moments_stale = True
@@ -291,7 +303,7 @@ class FusedAdam(torch.optim.Optimizer):
                 with ops._Timed("hbm_sumsq_clip_adam"):
                     ops.sumsq(f["g"], f["partial"])
                     ops.clip_adam(f["p"], f["g"], f["m"], f["v"], f["partial"], scale, group["max_grad_norm"], group["lr"], b1, b2,
-                                  group["eps"], f["step"], f["norm"])
+                                  group["eps"], f["step"], f["norm"], poison_reset=f["poison"])
             for p in f["params"]:
                 self.state[p]["step"] += 1
         L.PARAM_EPOCH[0] += 1      # packed bf16 / transposed weight shadows must be refreshed

@@ -23,3 +23,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fresh_spin_failure_bookkeeping():
+    """ops counts launches with bounded spins that gave up and switches those schedules off for the process after a few: tests that provoke
+    failures must not leak that state into the next test."""
+    from molecular_vae_amd import ops
+    ops.PERSIST_STATS.update(failures=0, reruns=0, disabled=False)
+    ops._PERSIST_WARNED[0] = False
+    del ops._PERSIST_PENDING[:]
+    yield

@@ -407,16 +407,19 @@ def test_persistent_dataflow_counted_waits_equal_the_drained_form(monkeypatch):
 
 def test_persistent_dataflow_failed_hand_off_is_reported_not_hung(monkeypatch):
     """Bounded spins: with the poll budget cut to ONE round (MVAE_PERSIST_SPIN=1) a consumer gives up at the first flag that is not there yet,
-    every workgroup drains, the launch ENDS, and the status record turns into an MvaeError at the next check -- never a hang; the next
-    launch with the normal budget is fine."""
+    every workgroup drains, the launch ENDS -- never a hang -- and the call (no poison slot given: it verifies its own launch) warns, runs the
+    pass again on the wavefront schedule and returns CORRECT results; the next launch with the normal budget is fine."""
     run, (T, B, H, NL) = _persist_case(16, seed=5)
+    a = run(False)
     monkeypatch.setenv("MVAE_PERSIST_SPIN", "1")
-    run(True)
-    with pytest.raises(LL.MvaeError):
-        ops.persist_check(sync=True)
+    with pytest.warns(RuntimeWarning, match="gave up"):
+        q = run(True)
+    assert ops.PERSIST_STATS["failures"] == 1 and ops.PERSIST_STATS["reruns"] == 1 and not ops.PERSIST_STATS["disabled"]
+    for l in range(NL):
+        assert torch.equal(a["hs"][l], q["hs"][l]) and torch.equal(a["gates"][l], q["gates"][l]), l       # the re-run IS the wavefront schedule
     monkeypatch.delenv("MVAE_PERSIST_SPIN")
-    a, p = run(False), run(True)
-    ops.persist_check(sync=True)
+    p = run(True)
+    assert ops.PERSIST_STATS["failures"] == 1
     assert _close_bf16(a["hs"][3][:, :, :H], p["hs"][3][:, :, :H])
 
 
@@ -575,17 +578,28 @@ def test_persistent_dataflow_backward_counted_waits_equal_the_drained_form(monke
 
 
 def test_persistent_dataflow_backward_failed_hand_off_is_reported_not_hung(monkeypatch):
-    """Poll budget of ONE round: somebody gives up at the first flag / partial that is not there yet, every workgroup drains, the launch ends
-    and the status record becomes an MvaeError; the next launch with the normal budget is fine."""
+    """Poll budget of ONE round: somebody gives up at the first flag / partial that is not there yet, every workgroup drains, the launch ends;
+    the call warns, re-runs the pass on the wavefront schedule (correct dG) and counts the failure; three failures switch the spinning
+    schedules off for the process; the next launch with the normal budget is fine."""
     run, (T, B, H, NL) = _persist_bwd_case(16, seed=5)
+    a = run(False)
     monkeypatch.setenv("MVAE_PERSIST_SPIN", "1")
-    run(True)
-    with pytest.raises(LL.MvaeError):
-        ops.persist_check(sync=True)
+    with pytest.warns(RuntimeWarning, match="gave up"):
+        q = run(True)
+    for l in range(NL):
+        assert torch.equal(a[l], q[l]), l
+    assert ops.PERSIST_STATS["failures"] == 1 and ops.PERSIST_STATS["reruns"] == 1
     monkeypatch.delenv("MVAE_PERSIST_SPIN")
-    a, p = run(False), run(True)
-    ops.persist_check(sync=True)
-    assert _close_rel(a[0][:, :, :4 * H], p[0][:, :, :4 * H], 2.0 ** -6)
+    p = run(True)
+    assert _close_rel(a[0][:, :, :4 * H], p[0][:, :, :4 * H], 2.0 ** -6) and ops.PERSIST_STATS["failures"] == 1
+    monkeypatch.setenv("MVAE_PERSIST_SPIN", "1")
+    with pytest.warns(RuntimeWarning):
+        run(True); run(True)
+    assert ops.PERSIST_STATS["failures"] == 3 and ops.PERSIST_STATS["disabled"]
+    monkeypatch.delenv("MVAE_PERSIST_SPIN")
+    n0 = ops.PERSIST_STATS["bwd_launches"]
+    r = run(None)                                         # default choice: the schedule is off now -> wavefront
+    assert ops.PERSIST_STATS["bwd_launches"] == n0 and all(torch.equal(a[l], r[l]) for l in range(NL))
 
 
 def test_persistent_backward_is_refused_off_its_shape_and_switched_by_its_knob(monkeypatch):
@@ -720,7 +734,7 @@ def test_layer_concurrent_row_resident_encoder_passes_equal_the_layer_by_layer_f
         return b
     n0 = ops.PERSIST_STATS["rowres_pipe"]
     a, p = run("0"), run("1")
-    assert ops.PERSIST_STATS["rowres_pipe"] == n0 + 1
+    assert ops.PERSIST_STATS["rowres_pipe"] == n0 + 2        # the forward AND the backward pass of run("1") reported a status record (= took the pipelined form)
     for k, tol in (("hs", 2e-6), ("cs", 2e-6), ("gates", 2e-6), ("dG", 2e-5)):
         for l in range(NL):
             assert rel(a[k][l].cpu().numpy(), p[k][l].cpu().numpy()) < tol, (k, l, float((a[k][l] - p[k][l]).abs().max()))

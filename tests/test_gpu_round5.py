@@ -158,3 +158,118 @@ def test_moses_and_models2d_draw_their_noise_in_the_library(golden_dir):
     e2, _, _ = ops.normal_draw(17, 0, 16)
     rb, mub, lvb = m2(x, eps=torch.tensor(e2.reshape(8, 2), dtype=torch.float32, device=dev))
     assert torch.equal(mua, mub) and rel(ra.detach().cpu().numpy(), rb.detach().cpu().numpy()) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------- persistent kernels against the oracle
+@pytest.mark.parametrize("B", [128, 256])
+def test_persistent_dataflow_passes_vs_the_numpy_oracle(B):
+    """rnn_persist.hip / rnn_persist_bwd.hip at the shape they serve (LSTM 4 x 1024, bf16, b = 128; 256 = two passes) with B DISTINCT random
+    rows, T = 6, against oracle/np_oracle.lstm_fwd / lstm_bwd (models.py:156,164): every layer's h, c, saved gates, dG through the weight /
+    bias gradients it yields, and the input gradient -- the tolerance of the other bf16 LSTM cases (3e-2).  Both passes are REQUIRED to take
+    the dataflow schedule (the helper asserts the launch counters)."""
+    from test_gpu_parity import _lstm_case
+    errs = _lstm_case(torch.bfloat16, 6, B, 1024, 4, 16, seed=7, persist=True)
+    bad = {k: v for k, v in errs.items() if v > 3e-2}
+    assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------- a launch that gives up is survivable
+def _b128_step_setup(dtype=torch.bfloat16, B=128):
+    torch.manual_seed(21)
+    model = mv.MolecularVAE(dtype=dtype).to(dev)
+    opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0)
+    lf = mv.make_loss_function(120)
+    idx = torch.randint(0, 35, (B, 120), generator=torch.Generator().manual_seed(3)).to(dev)
+    ohe = torch.nn.functional.one_hot(idx, 35).float()
+    eps = (1e-2 * torch.randn(B, 292, generator=torch.Generator().manual_seed(4))).to(dev)
+    return model, opt, lf, idx, ohe, eps
+
+
+@pytest.mark.parametrize("knob", ["MVAE_PERSIST_SPIN", "MVAE_ROWRES_SPIN"])
+def test_training_step_whose_persistent_launch_gave_up_is_skipped_on_the_device(knob, monkeypatch):
+    """b = 128 (the per-rank shape of configs[2]): a decoder dataflow pass (MVAE_PERSIST_SPIN=1) or a layer-concurrent encoder pass
+    (MVAE_ROWRES_SPIN=1) that gives up stores a NaN into the optimiser's poison slot; mvae_clip_adam then leaves parameters and moments
+    untouched (bit for bit) and counts the skip -- no exception, no host wait inside the step; the poison slot is clean again, the next step
+    trains normally, and after three failures the spinning schedules are off and the step runs on the wavefront / layer-by-layer forms."""
+    model, opt, lf, idx, ohe, eps = _b128_step_setup()
+    mv.train_step(model, opt, lf, idx, ohe, eps=eps)
+    torch.cuda.synchronize()
+    f = opt._flat[0]
+    assert float(opt.skipped_steps) == 0 and float(f["poison"]) == 0.0
+    n0 = dict(ops.PERSIST_STATS)
+    assert n0["launches"] >= 1 and n0["bwd_launches"] >= 1 and n0["rowres_pipe"] >= 2         # the schedules under test are the ones running
+    p0, m0 = f["p"].clone(), f["m"].clone()
+    monkeypatch.setenv(knob, "1")
+    with pytest.warns(RuntimeWarning, match="gave up"):
+        mv.train_step(model, opt, lf, idx, ohe, eps=eps)
+        torch.cuda.synchronize()
+        ops.persist_check(sync=True)
+    assert torch.equal(f["p"], p0) and torch.equal(f["m"], m0)                                 # the update did not happen
+    assert float(opt.skipped_steps) == 1 and float(f["poison"]) == 0.0 and not np.isfinite(float(opt.last_grad_norm))
+    assert ops.PERSIST_STATS["failures"] >= 1 and ops.PERSIST_STATS["reruns"] == 0             # nothing waited, nothing was re-run
+    monkeypatch.delenv(knob)
+    if not ops.PERSIST_STATS["disabled"]:
+        mv.train_step(model, opt, lf, idx, ohe, eps=eps)
+        torch.cuda.synchronize()
+        assert float(opt.skipped_steps) == 1 and not torch.equal(f["p"], p0) and np.isfinite(float(opt.last_grad_norm))
+    # enough failures: the schedules switch themselves off and training goes on
+    monkeypatch.setenv(knob, "1")
+    with pytest.warns(RuntimeWarning):
+        for _ in range(3):
+            mv.train_step(model, opt, lf, idx, ohe, eps=eps)
+            torch.cuda.synchronize()
+            ops.persist_check(sync=True)
+    assert ops.PERSIST_STATS["disabled"]
+    before = dict(ops.PERSIST_STATS)
+    p1 = f["p"].clone()
+    mv.train_step(model, opt, lf, idx, ohe, eps=eps)
+    torch.cuda.synchronize()
+    assert ops.persist_check(sync=True) == 0 and not torch.equal(f["p"], p1)
+    for k in ("launches", "bwd_launches", "rowres_pipe"):
+        assert ops.PERSIST_STATS[k] == before[k], k
+
+
+def test_evaluation_forward_re_runs_a_pass_that_gave_up(monkeypatch):
+    """No optimiser in sight (no_grad forward): the call waits for the status record of its persistent launch and, when it gave up, runs the
+    pass again without spins -- the caller gets the wavefront schedule's outputs and a warning."""
+    model, opt, lf, idx, ohe, eps = _b128_step_setup()
+    model.eval()
+    with torch.no_grad():
+        ops.PERSIST_DEFAULT = "0"
+        try:
+            want, mu0, _ = model(idx, eps=eps)
+        finally:
+            ops.PERSIST_DEFAULT = "1"
+        n0 = ops.PERSIST_STATS["launches"]
+        got, mu1, _ = model(idx, eps=eps)
+        assert ops.PERSIST_STATS["launches"] == n0 + 1
+        assert rel(got.cpu().numpy(), want.cpu().numpy()) < 2e-2 and rel(mu1.cpu().numpy(), mu0.cpu().numpy()) < 1e-5
+        monkeypatch.setenv("MVAE_PERSIST_SPIN", "1")
+        monkeypatch.setenv("MVAE_ROWRES_SPIN", "1")
+        with pytest.warns(RuntimeWarning, match="gave up"):
+            again, mu2, _ = model(idx, eps=eps)
+        assert ops.PERSIST_STATS["reruns"] >= 1
+        assert torch.equal(again, want) and torch.equal(mu2, mu0)
+
+
+def test_no_status_is_read_where_no_spinning_kernel_ran():
+    """the host used to re-derive which schedule the library took and read a status word the library might never have written
+    (sequence length > 256, > 64 rows per table block, dropout, a dh_last ...).  The library now reports the status location itself
+    (status_out): an encoder with i = 260 -- served by the wavefront / layer-by-layer forms -- runs forward and backward without any
+    spurious failure report and equals the oracle."""
+    dims = dict(i=260, o=16, c=12, emb=30, h_enc=72, n_enc=3, h_dec=32, n_dec=2)
+    shapes = ip.molvae_shapes(dims["i"], dims["o"], dims["c"], dims["emb"], dims["h_enc"], dims["n_enc"], dims["h_dec"], dims["n_dec"])
+    params = ip.init_params(shapes, 77, 2.0, np.float32)
+    enc, dec = gh.build_modules(dims, params, torch.float32)
+    B = 8
+    idx = ip.seeded_indices(5, B, dims["i"], dims["c"]); eps = ip.seeded_eps(5, B, dims["o"], dtype=np.float64)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        out = gh.run_hip(enc, dec, idx, eps, dims["i"])
+        assert ops.persist_check(sync=True) == 0
+    ref = O.molvae_loss_and_grads({k: v.astype(np.float64) for k, v in params.items()}, idx, eps, max_len=dims["i"], num_lstm=3, num_gru=2)
+    assert abs(out["loss"] - ref["loss"]) < 1e-5 * abs(ref["loss"])
+    worst = max(gh.grad_report(out["grads"], ref["grads"]).values())
+    assert worst < 1e-3, worst
+    assert ops.PERSIST_STATS["failures"] == 0

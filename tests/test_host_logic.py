@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     # sizes computed by hand from include/mvae.h (LP64): guards the ctypes mirror against drift
-    assert ctypes.sizeof(L.RnnFwdDesc) == 7 * 4 + 4 + 8 * 4 + (8 * 3 + 8) + 8 * (8 * 4) + 8 * 8 + 8 * 8 + 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + (8 * 8 * 2 + 8) + 16
-    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + (8 * 4 + 8) + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3 + 16 + (8 * 8 + 8) + 16
+    assert ctypes.sizeof(L.RnnFwdDesc) == 7 * 4 + 4 + 8 * 4 + (8 * 3 + 8) + 8 * (8 * 4) + 8 * 8 + 8 * 8 + 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + (8 * 8 * 2 + 8) + 16 + 16
+    assert ctypes.sizeof(L.RnnBwdDesc) == 6 * 4 + 8 * (8 * 4) + 8 + 16 + (8 * 4 + 8) + 8 * 8 + 8 * 8 + 8 + 8 * 8 + 8 + 8 * 8 * 3 + 8 + 8 * 8 * 3 + 16 + (8 * 8 + 8) + 16 + 16
     # ... and against what the compiler laid out (the loader refuses a mismatch as well)
     lib = L.load()
     for which, st in enumerate((L.RnnFwdDesc, L.RnnBwdDesc, L.GemmTnProblem)):
@@ -213,19 +213,19 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     assert lib.mvae_gemm_tn_colsum(8, 8, 8, p, 8, p, 8, p, 8, 0, None, 0, None, 0, None) == INV
     # recurrent stacks: empty descriptor, unknown cell, zero sizes, a missing save buffer
     d = L.RnnFwdDesc()
-    assert lib.mvae_rnn_fwd(None, None) == INV
+    assert lib.mvae_rnn_fwd(None, None, None) == INV
     d.cell = 9
-    assert lib.mvae_rnn_fwd(C.byref(d), None) == UNS
+    assert lib.mvae_rnn_fwd(C.byref(d), None, None) == UNS
     d.cell, d.dtype, d.layers, d.T, d.B, d.H = L.CELL_LSTM, L.MVAE_BF16, 1, 0, 4, 8
-    assert lib.mvae_rnn_fwd(C.byref(d), None) == INV
+    assert lib.mvae_rnn_fwd(C.byref(d), None, None) == INV
     d.T = 3
-    assert lib.mvae_rnn_fwd(C.byref(d), None) == INV            # no weights / outputs
+    assert lib.mvae_rnn_fwd(C.byref(d), None, None) == INV            # no weights / outputs
     d.layers = L.MAX_LAYERS + 1
-    assert lib.mvae_rnn_fwd(C.byref(d), None) == INV
+    assert lib.mvae_rnn_fwd(C.byref(d), None, None) == INV
     b = L.RnnBwdDesc()
-    assert lib.mvae_rnn_bwd(None, None) == INV
+    assert lib.mvae_rnn_bwd(None, None, None) == INV
     b.cell, b.dtype, b.layers, b.T, b.B, b.H = L.CELL_LSTM, 5, 1, 3, 4, 8
-    assert lib.mvae_rnn_bwd(C.byref(b), None) == INV
+    assert lib.mvae_rnn_bwd(C.byref(b), None, None) == INV
     # helpers
     assert lib.mvae_onehot_tb(p, 4, 4, 30, p, 30, None) == INV             # leading dimension not a multiple of 8
     assert lib.mvae_onehot_tb(p, 4, 4, 40, p, 32, None) == INV             # table wider than the row
