@@ -51,7 +51,7 @@ extern "C" {
 #define MVAE_MAX_LAYERS 8
 
 int mvae_abi_version(void);
-/* sizeof of the descriptor structs as THIS library was compiled (0: mvae_rnn_fwd_desc, 1: mvae_rnn_bwd_desc, 2: mvae_gemm_tn_problem, 3: mvae_pack_job;
+/* sizeof of the descriptor structs as THIS library was compiled (0: mvae_rnn_fwd_desc, 1: mvae_rnn_bwd_desc, 2: mvae_gemm_tn_problem, 3: mvae_pack_job, 4: mvae_gemm_tn_f32_problem;
  * anything else: 0) -- a binding checks its own mirror of the structs against it at load time. */
 size_t mvae_struct_size(int which);
 const char* mvae_status_string(int status);
@@ -111,6 +111,24 @@ int mvae_gemm_tn_grouped(int n, const mvae_gemm_tn_problem* problems, void* ws, 
  * side stream that must leave compute units to the latency-bound launches of the main stream (the per-rank batch of a data-parallel job:
  * K = T * b is short, the encoder's backward runs beside it). */
 int mvae_gemm_tn_grouped_capped(int n, const mvae_gemm_tn_problem* problems, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
+/* Exact-f32 TN contractions of DIFFERENT shapes in ONE launch (+ one reduction launch for all of their split-K slabs): the parameter-gradient
+ * GEMMs of the encoder's backward pass -- Lambda heads, dense_1, the three Conv1d weight gradients, the LSTM(72) stack's dW_ih / dW_hh
+ * (models.py:87-88,122,118-120,117) -- are a dozen small dependent-free products whose only consumer is the optimiser; launched one by one
+ * each leaves most of the chip idle.  Problem i: C[M,N] (+)= A^T . B over K rows, A / B row-major fp32 with optional row groups (row r starts
+ * at (r / group) * gstride + (r % group) * ld when group > 0: the overlapping windows of a channels-last Conv1d), colsum_out (optional):
+ * column sums of A through a virtual ones column (as mvae_gemm_tn_f32_colsum), x3 != 0: products as 3 x bf16 (MVAE_F32X3).  lda, ldb and the
+ * group strides multiples of 4, bases 16-byte aligned.  At most MVAE_TN_F32_MULTI_MAX problems; outputs must not overlap. */
+#define MVAE_TN_F32_MULTI_MAX 16
+typedef struct {
+  int M, N; int64_t K;
+  const float* A; int64_t lda; int a_group; int64_t a_gstride;
+  const float* B; int64_t ldb; int b_group; int64_t b_gstride;
+  float* C; int64_t ldc; int accumulate;
+  float* colsum_out; int colsum_accumulate;
+  int x3;
+} mvae_gemm_tn_f32_problem;
+size_t mvae_gemm_tn_f32_multi_workspace(int n, const mvae_gemm_tn_f32_problem* problems);
+int mvae_gemm_tn_f32_multi(int n, const mvae_gemm_tn_f32_problem* problems, void* ws, size_t ws_bytes, void* stream);
 size_t mvae_gemm_tn_colsum_workspace(int M, int N, int K);
 int mvae_gemm_tn_colsum(int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
                         float* colsum_out, int colsum_accumulate, void* ws, size_t ws_bytes, void* stream);
@@ -155,6 +173,10 @@ size_t mvae_scatter_rows_tb_workspace(int B, int L, int nrows, int W);
  * With it the scatter above is the TN contraction  dtable = out^T . d  (mvae_gemm_tn, M = nrows): the bf16 gradient sequence is read
  * once at GEMM streaming rate and summed in fp32 by the MFMAs. */
 int mvae_onehot_tb(const int64_t* idx, int B, int L, int nrows, void* out, int64_t ld, void* stream);
+/* fp32 form, rows in the order of idx itself: out[r, c] = (idx[r] == c) for r < n, c < ld (ld >= nrows, ld % 4 == 0).  The exact-f32 table gradient
+ * of the encoder (models.py:116 Embedding folded into the LSTM's layer-0 projection) is then one problem of mvae_gemm_tn_f32_multi: A = out,
+ * B = the layer-0 pre-activation gradients addressed through row groups (row b * L + t of B = dG[t][b]). */
+int mvae_onehot_f32(const int64_t* idx, int64_t n, int nrows, float* out, int64_t ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Recurrent stack (K2, K7, K10, K12 of SURVEY.md): torch.nn.LSTM / nn.GRU, batch-major module semantics,
@@ -331,6 +353,12 @@ int mvae_conv1d_act_fwd(int act, int B, int W, int ldx, int64_t x_bs, int Cout, 
 int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
                         const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                         void* ws, size_t ws_bytes, void* stream);
+/* dw == NULL in mvae_conv1d_*_bwd: only dzp and dx are produced; the layer's weight / bias gradient is then described by mvae_conv1d_dw_problem
+ * as one problem of mvae_gemm_tn_f32_multi (dwp [Cout][k * ldx]: the gradient in the packed layout of wp; db: bias gradient) and brought into
+ * the parameter layout dw [Cout][Cin][k] by mvae_conv1d_unpack_dw -- so that ALL parameter gradients of an encoder share one launch. */
+int mvae_conv1d_dw_problem(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dzp, const float* x, float* dwp,
+                           float* db, int x3, mvae_gemm_tn_f32_problem* out);
+int mvae_conv1d_unpack_dw(int Cin, int Cout, int k, const float* dwp, int ldx, float* dw, void* stream);
 int mvae_conv1d_selu_bwd(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
                          const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                          void* ws, size_t ws_bytes, void* stream);

@@ -68,6 +68,12 @@ class GemmTnProblem(C.Structure):
                 ("C", _vp), ("ldc", _i64), ("accumulate", _i), ("colsum_out", _vp), ("colsum_accumulate", _i)]
 
 
+class GemmTnF32Problem(C.Structure):
+    _fields_ = [("M", _i), ("N", _i), ("K", _i64), ("A", _vp), ("lda", _i64), ("a_group", _i), ("a_gstride", _i64),
+                ("B", _vp), ("ldb", _i64), ("b_group", _i), ("b_gstride", _i64), ("C", _vp), ("ldc", _i64), ("accumulate", _i),
+                ("colsum_out", _vp), ("colsum_accumulate", _i), ("x3", _i)]
+
+
 class PackJob(C.Structure):
     _fields_ = [("kind", _i), ("src_dtype", _i), ("dst_dtype", _i), ("R", _i), ("C", _i), ("block0", _i),
                 ("src", _vp), ("lds", _i64), ("dst", _vp), ("ldd", _i64), ("dstT", _vp), ("ldt", _i64), ("src2", _vp)]
@@ -91,6 +97,7 @@ SIGNATURES = {
     "mvae_scatter_rows_tb": (_i, [_i, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "mvae_scatter_rows_tb_workspace": (_sz, [_i, _i, _i, _i]),
     "mvae_onehot_tb": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp]),
+    "mvae_onehot_f32": (_i, [_vp, _i64, _i, _vp, _i64, _vp]),
     "mvae_rnn_fwd": (_i, [C.POINTER(RnnFwdDesc), _vp, C.POINTER(_vp)]),
     "mvae_rnn_fwd_persist_workspace": (_sz, [C.POINTER(RnnFwdDesc)]),
     "mvae_dropout_keep": (_i, [C.c_uint32, C.c_uint32, _f]),
@@ -100,6 +107,10 @@ SIGNATURES = {
     "mvae_gemm_tn_grouped_workspace": (_sz, [_i, C.POINTER(GemmTnProblem)]),
     "mvae_gemm_tn_grouped": (_i, [_i, C.POINTER(GemmTnProblem), _vp, _sz, _vp]),
     "mvae_gemm_tn_grouped_capped": (_i, [_i, C.POINTER(GemmTnProblem), _i, _vp, _sz, _vp]),
+    "mvae_gemm_tn_f32_multi_workspace": (_sz, [_i, C.POINTER(GemmTnF32Problem)]),
+    "mvae_gemm_tn_f32_multi": (_i, [_i, C.POINTER(GemmTnF32Problem), _vp, _sz, _vp]),
+    "mvae_conv1d_dw_problem": (_i, [_i, _i, _i, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(GemmTnF32Problem)]),
+    "mvae_conv1d_unpack_dw": (_i, [_i, _i, _i, _vp, _i, _vp, _vp]),
     "mvae_gemm_tn_colsum_workspace": (_sz, [_i, _i, _i]),
     "mvae_gemm_tn_colsum": (_i, [_i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp, _sz, _vp]),
     "mvae_rnn_bwd": (_i, [C.POINTER(RnnBwdDesc), _vp, C.POINTER(_vp)]),
@@ -167,7 +178,7 @@ def load():
         fn.argtypes = args
     if lib.mvae_abi_version() != ABI_VERSION:
         raise MvaeError("libmvae_hip.so ABI version mismatch")
-    for which, st in enumerate((RnnFwdDesc, RnnBwdDesc, GemmTnProblem, PackJob)):
+    for which, st in enumerate((RnnFwdDesc, RnnBwdDesc, GemmTnProblem, PackJob, GemmTnF32Problem)):
         if lib.mvae_struct_size(which) != C.sizeof(st):
             raise MvaeError(f"{st.__name__}: ctypes mirror is {C.sizeof(st)} bytes, the library's struct {lib.mvae_struct_size(which)}")
     _lib = lib

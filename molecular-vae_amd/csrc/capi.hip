@@ -17,6 +17,7 @@ size_t mvae_struct_size(int which) {
     case 1: return sizeof(mvae_rnn_bwd_desc);
     case 2: return sizeof(mvae_gemm_tn_problem);
     case 3: return sizeof(mvae_pack_job);
+    case 4: return sizeof(mvae_gemm_tn_f32_problem);
     default: return 0;
   }
 }

@@ -112,7 +112,7 @@ int mvae_conv1d_selu_bwd(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout,
 int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dy, const float* y,
                         const float* x, const float* wq, float* dzp, float* dw, float* db, float* dx, int64_t lddx,
                         void* ws, size_t ws_bytes, void* stream) {
-  if (!dy || !y || !x || !dzp || !dw || !db || !ws) return MVAE_ERR_INVALID;
+  if (!dy || !y || !x || !dzp || (dw && !db) || !ws) return MVAE_ERR_INVALID;      // dw == NULL: the weight gradient is left to the caller (mvae_conv1d_dw_problem)
   const bool x3 = (act & MVAE_CONV_BWD_X3) != 0;
   act &= ~MVAE_CONV_BWD_X3;
   if (act != MVAE_ACT_NONE && act != MVAE_ACT_SELU && act != MVAE_ACT_RELU) return MVAE_ERR_INVALID;
@@ -132,15 +132,39 @@ int mvae_conv1d_act_bwd(int act, int B, int W, int Cin, int ldx, int64_t x_bs, i
   MVAE_CHECK_HIP(hipGetLastError());
   // dwp[o][kc] = sum over output positions of dz[(b,w)][o] * window(b,w)[kc]; the bias gradient db[o] = sum over positions of dz[..][o] rides
   // along as the GEMM's virtual ones column (the x3 form: ~16 mantissa bits, like the rest of that GEMM) -- no separate column-sum launches
-  const float* dz0 = dzp + (long)(k - 1) * ldo;
-  if ((rc = launch_gemm_tn_f32(Cout, k * ldx, B * Wout, dz0, ldo, Wout, (long)Wp * ldo, x, ldx, Wout, x_bs, dwp, (long)k * ldx, 0, gws, gws_bytes, st, x3, db, 0))) return rc;
-  hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3(cgrid((long)Cout * Cin * k)), dim3(256), 0, st, Cin, Cout, k, dwp, ldx, dw);
-  MVAE_CHECK_HIP(hipGetLastError());
+  if (dw) {
+    const float* dz0 = dzp + (long)(k - 1) * ldo;
+    if ((rc = launch_gemm_tn_f32(Cout, k * ldx, B * Wout, dz0, ldo, Wout, (long)Wp * ldo, x, ldx, Wout, x_bs, dwp, (long)k * ldx, 0, gws, gws_bytes, st, x3, db, 0))) return rc;
+    hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3(cgrid((long)Cout * Cin * k)), dim3(256), 0, st, Cin, Cout, k, dwp, ldx, dw);
+    MVAE_CHECK_HIP(hipGetLastError());
+  }
   if (dx) {
     // dx[(b,w)][c] = sum_{j,o} dzp[b][w + j][o] * w[o][c][k-1-j]: full correlation = the forward GEMM on the padded dz
     if ((rc = launch_gemm_nt_grouped(x3 ? MVAE_F32X3 : MVAE_F32, B * W, Cin, k * ldo, dzp, ldo, W, (long)Wp * ldo, (long)B * Wp * ldo, wq, (long)k * ldo, dx, lddx,
                                      MVAE_F32, nullptr, MVAE_ACT_NONE, 0, gws, gws_bytes, st))) return rc;
   }
+  return MVAE_OK;
+}
+
+// The weight / bias gradient of the same layer as a PROBLEM of mvae_gemm_tn_f32_multi: dwp [Cout][k * ldx] (packed like wp) = dz^T . windows(x),
+// db = column sums of dz, from the dzp buffer a previous mvae_conv1d_act_bwd(..., dw = NULL, ...) call filled.  mvae_conv1d_unpack_dw turns dwp
+// into the parameter layout dw [Cout][Cin][k] afterwards.
+int mvae_conv1d_dw_problem(int B, int W, int Cin, int ldx, int64_t x_bs, int Cout, int ldo, int k, const float* dzp, const float* x, float* dwp,
+                           float* db, int x3, mvae_gemm_tn_f32_problem* out) {
+  if (!dzp || !x || !dwp || !db || !out || B < 1 || Cin < 1 || Cout < 1 || k < 1 || W < k || ldx < Cin || ldo < Cout || (ldx & 3) || (ldo & 3) ||
+      (x_bs & 3) || x_bs < (int64_t)W * ldx) return MVAE_ERR_INVALID;
+  const int Wout = W - k + 1, Wp = Wout + 2 * (k - 1);
+  out->M = Cout; out->N = k * ldx; out->K = (int64_t)B * Wout;
+  out->A = dzp + (long)(k - 1) * ldo; out->lda = ldo; out->a_group = Wout; out->a_gstride = (int64_t)Wp * ldo;
+  out->B = x; out->ldb = ldx; out->b_group = Wout; out->b_gstride = x_bs;
+  out->C = dwp; out->ldc = (int64_t)k * ldx; out->accumulate = 0;
+  out->colsum_out = db; out->colsum_accumulate = 0; out->x3 = x3 ? 1 : 0;
+  return MVAE_OK;
+}
+int mvae_conv1d_unpack_dw(int Cin, int Cout, int k, const float* dwp, int ldx, float* dw, void* stream) {
+  if (!dwp || !dw || Cin < 1 || Cout < 1 || k < 1 || ldx < Cin) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3(cgrid((long)Cout * Cin * k)), dim3(256), 0, (hipStream_t)stream, Cin, Cout, k, dwp, ldx, dw);
+  MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }
 

@@ -1073,6 +1073,18 @@ __global__ __launch_bounds__(256) void mask_rows_tb_kernel(int T_, int B, long l
   }
 }
 
+// fp32 one-hot rows in the order of idx itself (row r = flat position in idx): the exact-f32 table gradient dtable = onehot^T . d as a TN problem
+__global__ __launch_bounds__(256) void onehot_f32_kernel(const int64_t* idx, long n, int nrows, float* out, long ld) {
+  const int gpr = (int)(ld / 4);
+  const long tot = n * gpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const long row = i / gpr; const int c0 = (int)(i - row * gpr) * 4;
+    long id = idx[row];
+    id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
+    const int e = (int)id - c0;
+    *reinterpret_cast<float4*>(out + row * ld + c0) = make_float4(e == 0 ? 1.f : 0.f, e == 1 ? 1.f : 0.f, e == 2 ? 1.f : 0.f, e == 3 ? 1.f : 0.f);
+  }
+}
 // one thread per (row, 8-column group): 16-byte stores
 __global__ __launch_bounds__(256) void onehot_tb_kernel(const int64_t* idx, int B, int L, int nrows, bf16_t* out, long ld) {
   const int gpr = (int)(ld / 8);
@@ -1167,6 +1179,12 @@ int mvae_timesum(int dtype, int T, int B, int W, const void* X, float* out, void
       hipLaunchKernelGGL(timesum_bf16x8_kernel, dim3(grid_for(BW / 8, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
     else hipLaunchKernelGGL((timesum_kernel<bf16_t>), dim3(grid_for(BW, 256, 8192)), dim3(256), 0, st, T, BW, (const bf16_t*)X, out);
   } else return MVAE_ERR_INVALID;
+  MVAE_CHECK_HIP(hipGetLastError());
+  return MVAE_OK;
+}
+int mvae_onehot_f32(const int64_t* idx, int64_t n, int nrows, float* out, int64_t ld, void* stream) {
+  if (!idx || !out || n < 1 || nrows < 1 || ld < nrows || (ld % 4) || (reinterpret_cast<uintptr_t>(out) & 15)) return MVAE_ERR_INVALID;
+  hipLaunchKernelGGL(onehot_f32_kernel, dim3(grid_for((long)n * (ld / 4))), dim3(256), 0, (hipStream_t)stream, idx, (long)n, nrows, out, (long)ld);
   MVAE_CHECK_HIP(hipGetLastError());
   return MVAE_OK;
 }

@@ -573,16 +573,11 @@ constexpr int TNF_BM = 64, TNF_KS = 32, TNF_LD = 80;
 // stage -- exactly the eight values the fp32 form already reads for its eight 16x16x4 MFMAs.  12 bf16 MFMAs per stage instead of 32 fp32 ones.
 // CS: instantiation that can produce the column sums of A through a virtual ones column of B (p.ones_col); the plain instantiation carries no
 // trace of it -- this loop has no VALU slack (four compares and selects per staged chunk cost the f32 decoder's weight gradients +28 %).
-template <bool X3, bool CS = false>
-__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
-  __shared__ float As[2][TNF_KS * TNF_LD];
-  __shared__ float Bs[2][TNF_KS * TNF_LD];
+template <bool X3, bool CS>
+__device__ __forceinline__ void gemm_tn_f32_body(const GemmArgs& p, int tile, int split, float (&As)[2][TNF_KS * TNF_LD], float (&Bs)[2][TNF_KS * TNF_LD]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntile);
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * TNF_BM, n0 = tn * TNF_BM;
-  const int split = blockIdx.y;
   const long rbeg = (long)split * p.kper;
   const long rend = (rbeg + p.kper < (long)p.K) ? (rbeg + p.kper) : (long)p.K;
   const float* A = reinterpret_cast<const float*>(p.A);
@@ -721,9 +716,61 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
       }
     }
 }
+template <bool X3, bool CS = false>
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmArgs p) {
+  __shared__ float As[2][TNF_KS * TNF_LD];
+  __shared__ float Bs[2][TNF_KS * TNF_LD];
+  gemm_tn_f32_body<X3, CS>(p, xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), blockIdx.y, As, Bs);
+}
+
+// ---- several problems of different shapes in ONE launch (mvae_gemm_tn_f32_multi): the argument block carries every problem's GemmArgs (kernel
+// arguments: no device-side table to build or copy); block b serves problem g with first[g] <= b < first[g + 1], tile = local % tiles,
+// split = local / tiles.  flags[g]: bit 0 = x3, bit 1 = column sums.  One second launch sums every problem's split-K slabs (grid.y = problem).
+struct TnF32Multi {
+  GemmArgs p[MVAE_TN_F32_MULTI_MAX];
+  int first[MVAE_TN_F32_MULTI_MAX + 1];
+  int flags[MVAE_TN_F32_MULTI_MAX];
+  int n;
+};
+static_assert(sizeof(TnF32Multi) <= 4000, "kernel argument block");
+__global__ __launch_bounds__(256) void gemm_tn_f32_multi_kernel(TnF32Multi m) {
+  __shared__ float As[2][TNF_KS * TNF_LD];
+  __shared__ float Bs[2][TNF_KS * TNF_LD];
+  int g = 0;
+  while (g + 1 < m.n && (int)blockIdx.x >= m.first[g + 1]) ++g;          // workgroup-uniform
+  const GemmArgs& p = m.p[g];
+  const int local = (int)blockIdx.x - m.first[g], tiles = p.tiles_m * p.tiles_n;
+  const int split = local / tiles, tile = local - split * tiles;
+  switch (m.flags[g]) {
+    case 0: gemm_tn_f32_body<false, false>(p, tile, split, As, Bs); break;
+    case 1: gemm_tn_f32_body<true, false>(p, tile, split, As, Bs); break;
+    case 2: gemm_tn_f32_body<false, true>(p, tile, split, As, Bs); break;
+    default: gemm_tn_f32_body<true, true>(p, tile, split, As, Bs); break;
+  }
+}
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_multi_kernel(TnF32Multi m) {
+  const GemmArgs& p = m.p[blockIdx.y];
+  if (p.splits <= 1) return;
+  const long n = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / p.N), col = (int)(i - (long)row * p.N);
+    float v = 0.f;
+    for (int s = 0; s < p.splits; ++s) v += p.partial[(long)s * n + i];   // fixed order: deterministic
+    store_out(p.C, (long)row * p.ldc + col, p.c_dtype, v, p.accumulate);
+  }
+  if (p.colsum_out && p.colsum_partial) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.M; i += (long)gridDim.x * 256) {
+      float v = 0.f;
+      for (int s = 0; s < p.colsum_nparts; ++s) v += p.colsum_partial[(long)s * p.M + i];
+      p.colsum_out[i] = p.colsum_acc ? p.colsum_out[i] + v : v;
+    }
+  }
+}
 
 namespace {
-Plan make_plan_tn_f32(int M, int N, int R) {
+// `target`: workgroups this problem should offer (768 = two or three per CU when it has the chip to itself; a problem of a multi launch
+// gets its share of ~1536)
+Plan make_plan_tn_f32(int M, int N, int R, int target = 768) {
   Plan pl;
   pl.bm = TNF_BM;
   pl.tiles_m = (M + TNF_BM - 1) / TNF_BM; pl.tiles_n = (N + TNF_BM - 1) / TNF_BM;
@@ -731,8 +778,8 @@ Plan make_plan_tn_f32(int M, int N, int R) {
   long steps = (R + TNF_KS - 1) / TNF_KS;
   if (steps < 1) steps = 1;
   int splits = 1;
-  if (tiles < 512 && steps >= 16) {           // two or more workgroups per CU: the f32 MFMA stream of one tile is short on parallelism
-    splits = (int)((768 + tiles - 1) / tiles);
+  if (tiles < (target * 2) / 3 && steps >= 16) {           // two or more workgroups per CU: the f32 MFMA stream of one tile is short on parallelism
+    splits = (int)((target + tiles - 1) / tiles);
     const long maxs = steps / 8;
     if (splits > maxs) splits = (int)maxs;
     if (splits > 64) splits = 64;
@@ -794,6 +841,65 @@ int launch_gemm_tn_f32(int M, int N, int R, const float* A, long lda, int a_grou
   return MVAE_OK;
 }
 
+
+// ---- multi launcher (exact-f32 TN problems of different shapes in one launch; see gemm_tn_f32_multi_kernel)
+namespace {
+int tnf_multi_target(int n) { int t = 1536 / (n > 0 ? n : 1); return t < 96 ? 96 : (t > 768 ? 768 : t); }
+Plan tnf_multi_plan(const mvae_gemm_tn_f32_problem& q, int n) { return make_plan_tn_f32(q.M, q.colsum_out ? q.N + 1 : q.N, (int)q.K, tnf_multi_target(n)); }
+size_t tnf_multi_need(const mvae_gemm_tn_f32_problem& q, const Plan& pl) {
+  return pl.splits > 1 ? (((size_t)pl.splits * q.M * (q.N + (q.colsum_out ? 1 : 0)) * sizeof(float) + 255) & ~(size_t)255) : 0;
+}
+}  // namespace
+extern "C" size_t mvae_gemm_tn_f32_multi_workspace(int n, const mvae_gemm_tn_f32_problem* pr) {
+  if (n < 1 || n > MVAE_TN_F32_MULTI_MAX || !pr) return 0;
+  size_t b = 0;
+  for (int i = 0; i < n; ++i) if (pr[i].M > 0 && pr[i].N > 0 && pr[i].K >= 0 && pr[i].K < (1L << 31)) b += tnf_multi_need(pr[i], tnf_multi_plan(pr[i], n));
+  return b;
+}
+extern "C" int mvae_gemm_tn_f32_multi(int n, const mvae_gemm_tn_f32_problem* pr, void* ws, size_t ws_bytes, void* stream) {
+  if (n < 1 || n > MVAE_TN_F32_MULTI_MAX || !pr) return MVAE_ERR_INVALID;
+  if (mvae_gemm_tn_f32_multi_workspace(n, pr) > ws_bytes || (mvae_gemm_tn_f32_multi_workspace(n, pr) && !ws)) return MVAE_ERR_WORKSPACE;
+  TnF32Multi m;
+  m.n = n;
+  char* wsp = reinterpret_cast<char*>(ws);
+  int blocks = 0, any_split = 0;
+  long max_mn = 1;
+  for (int i = 0; i < n; ++i) {
+    const mvae_gemm_tn_f32_problem& q = pr[i];
+    if (q.M < 1 || q.N < 1 || q.K < 0 || q.K >= (1L << 31) || !q.A || !q.B || !q.C) return MVAE_ERR_INVALID;
+    if ((q.lda | q.ldb | q.a_gstride | q.b_gstride) & 3) return MVAE_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) return MVAE_ERR_INVALID;
+    const Plan pl = tnf_multi_plan(q, n);
+    GemmArgs& p = m.p[i];
+    p.A = q.A; p.B = q.B; p.C = q.C; p.bias = nullptr; p.partial = nullptr;
+    p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N; p.K = (int)q.K;
+    p.c_dtype = MVAE_F32; p.act = MVAE_ACT_NONE; p.accumulate = q.accumulate;
+    p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.kper = pl.kper;
+    p.a_group = q.a_group; p.a_gstride = q.a_gstride; p.b_group = q.b_group; p.b_gstride = q.b_gstride; p.a_total = 0; p.b_total = 0;
+    p.colsum_out = q.colsum_out; p.colsum_partial = nullptr; p.colsum_acc = q.colsum_accumulate; p.colsum_nparts = pl.splits; p.ones_col = q.colsum_out ? q.N : -1;
+    if (pl.splits > 1) {
+      p.partial = reinterpret_cast<float*>(wsp);
+      if (q.colsum_out) p.colsum_partial = p.partial + (size_t)pl.splits * q.M * q.N;
+      wsp += tnf_multi_need(q, pl);
+      any_split = 1;
+      if ((long)q.M * q.N > max_mn) max_mn = (long)q.M * q.N;
+    }
+    m.flags[i] = (q.x3 ? 1 : 0) | (q.colsum_out ? 2 : 0);
+    m.first[i] = blocks;
+    blocks += pl.tiles_m * pl.tiles_n * pl.splits;
+  }
+  m.first[n] = blocks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_tn_f32_multi_kernel, dim3(blocks), dim3(256), 0, st, m);
+  MVAE_CHECK_HIP(hipGetLastError());
+  if (any_split) {
+    int bx = (int)((max_mn + 255) / 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(gemm_splitk_reduce_multi_kernel, dim3(bx, n), dim3(256), 0, st, m);
+    MVAE_CHECK_HIP(hipGetLastError());
+  }
+  return MVAE_OK;
+}
 
 // ---- grouped launcher (see gemm_tn_bf16_256_grouped_kernel).  Every problem: bf16 K-major operands, fp32 C, N a multiple of 256, and --
 // for column sums -- exactly 4 tile columns (N == 1024).  Operands beyond 2 GiB (K * ld * 2 bytes) are not served here.

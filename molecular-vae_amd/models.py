@@ -240,10 +240,10 @@ def _params_key(params):
 
 
 DW_KSPLIT = "1"      # K-chunks of the grouped decoder weight-gradient launches (see _lstm_weight_grads)
-WGRAD_CAP = "192"      # workgroups of the grouped weight-gradient launches at small per-GPU batches (0: one per tile, released next to the encoder LSTM backward)
+WGRAD_CAP = "160"      # workgroups of the grouped weight-gradient launches at small per-GPU batches (0: one per tile, released next to the encoder LSTM backward)
 
 
-def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=None, max_workgroups=0):
+def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=None, max_workgroups=0, batch=None):
     """dW_ih, dW_hh, db of every layer from the saved pre-activation gradients dG [T*B, 4H] and layer outputs hs [T*B, H].
     Both dtypes contract straight from the K-major buffers (bf16: hardware-transposed LDS reads; f32: exact-f32 TN kernel)."""
     G4, TB = 4 * H, Lq * B
@@ -301,6 +301,18 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
             if not have_db:
                 ops.colsum_t(a, TB, G4, db, ldx=ldg)
             grads[f"{prefix}.bias_hh_l{l}"].copy_(db)
+        return
+    if batch is not None and dt == torch.float32 and H % 64:      # the narrow exact-f32 stack (the encoder): every contraction joins the caller's batch
+        for l in layers:                      # (the caller copies bias_ih -> bias_hh after batch.run())
+            a = dG[l].view(TB, ldg)
+            x = hs[l].view(TB, ldh)
+            if Lq > 1:
+                batch.add(a[B:], x, grads[f"{prefix}.weight_hh_l{l}"], G4, H, TB - B, lda=ldg, ldb=ldh)
+            if l > 0:
+                batch.add(a, hs[l - 1].view(TB, ldh), grads[f"{prefix}.weight_ih_l{l}"], G4, H, TB, lda=ldg, ldb=ldh, colsum_out=grads[f"{prefix}.bias_ih_l{l}"])
+            else:       # layer 0 has no W_ih product here (its input is the token table): the bias gradient = column sums of dG over ALL T * B rows
+                # rides on a 4-column product whose output nobody reads
+                batch.add(a, x, ws.get(f"{prefix}_dw_dummy", (G4, 4), torch.float32, dev), G4, 4, TB, lda=ldg, ldb=ldh, colsum_out=grads[f"{prefix}.bias_ih_l{l}"])
         return
     for l in layers:                          # f32: the exact-f32 TN kernel, same K-major operands
         a = dG[l].view(TB, ldg)
@@ -593,8 +605,15 @@ class _EncoderFn(torch.autograd.Function):
         ops.lambda_bwd(mulv, eps, dz, dmu, dlogv, dmulv, B, o)
         # dW = dy^T . x straight from the batch-major operands (exact-f32 TN kernel), db = column sums of dy as the GEMM's virtual ones column;
         # one GEMM per head (the column halves of dmulv), written into the parameters' own gradient slots
+        # Every GEMM that only produces PARAMETER gradients (heads, dense_1, the three convolutions, the LSTM stack: a dozen small contractions
+        # nobody but the optimiser waits for) is collected and runs as ONE launch at the end of this backward pass (ops.TnF32Batch); the launches
+        # left on the way are the input-gradient chain.  MVAE_ENC_DW_BATCH=0: one launch each, where it stands (A/B, tests).
+        batch = ops.TnF32Batch(dev) if L.knob("MVAE_ENC_DW_BATCH", "1") != "0" else None
         for k, nm in enumerate(("lmbd.z_mean", "lmbd.z_log_var")):
-            ops.gemm_tn_f32_colsum(dmulv[:, k * o:(k + 1) * o], d, grads[nm + ".weight"], grads[nm + ".bias"], o, 512, B, lda=2 * o, ldb=512)
+            if batch is not None:
+                batch.add(dmulv[:, k * o:(k + 1) * o], d, grads[nm + ".weight"], o, 512, B, lda=2 * o, ldb=512, colsum_out=grads[nm + ".bias"])
+            else:
+                ops.gemm_tn_f32_colsum(dmulv[:, k * o:(k + 1) * o], d, grads[nm + ".weight"], grads[nm + ".bias"], o, 512, B, lda=2 * o, ldb=512)
         dd = W("dd", (B, 512))
         ops.gemm_nt(dmulv, P["WmlT"], dd, B, 512, 2 * o, ldb=P["WmlT"].stride(0))
         ops.selu_bwd(dd, d)
@@ -602,7 +621,10 @@ class _EncoderFn(torch.autograd.Function):
         d1 = mod.dense_1[0]
         F = d1.in_features
         flat = W("flat", (B, F))
-        ops.gemm_tn_f32_colsum(dd, flat, grads["dense_1.0.weight"], grads["dense_1.0.bias"], 512, F, B)
+        if batch is not None:
+            batch.add(dd, flat, grads["dense_1.0.weight"], 512, F, B, colsum_out=grads["dense_1.0.bias"])
+        else:
+            ops.gemm_tn_f32_colsum(dd, flat, grads["dense_1.0.weight"], grads["dense_1.0.bias"], 512, F, B)
         dflat = W("dflat", (B, F))
         ops.gemm_nt(dd, P["W1T"], dflat, B, F, 512)
         fork.run_deferred(0)      # the decoder's upper-layer weight-gradient GEMMs: from here on our own launches are chip-filling too
@@ -620,12 +642,16 @@ class _EncoderFn(torch.autograd.Function):
         dzp3, dzp2, dzp1 = W("dzp3", (B * (W3 + 2 * k - 2), C3)), W("dzp2", (B * (W2 + 2 * k - 2), O2)), W("dzp1", (B * (W1 + 2 * k - 2), O1))
         # bf16 training mode: input-gradient GEMMs as 3 x bf16 products (forward conv stays exact fp32); MVAE_CONV_X3=0: A/B knob
         x3 = bool(mod.fast_grad_gemms) and L.knob("MVAE_CONV_X3", "1") != "0"
-        ops.conv1d_selu_bwd(B, W2, c3.in_channels, O2, W2 * O2, C3, C3, k, dy3, y3, y2, P["c3_wq"], dzp3,
-                            grads["conv_3.0.weight"], grads["conv_3.0.bias"], dy2, O2, x3=x3)
-        ops.conv1d_selu_bwd(B, W1, c2.in_channels, O1, W1 * O1, c2.out_channels, O2, k, dy2, y2, y1, P["c2_wq"], dzp2,
-                            grads["conv_2.0.weight"], grads["conv_2.0.bias"], dy1, O1, x3=x3)
-        ops.conv1d_selu_bwd(B, H, Lq, L1, Hp * L1, c1.out_channels, O1, k, dy1, y1, x1, P["c1_wq"], dzp1,
-                            grads["conv_1.0.weight"], grads["conv_1.0.bias"], dx1, L1, x3=x3)
+        for (n, Wi, Ci, ldx_, xbs, Co, ldo_, dy_, y_, x_, dzp_, dx_, lddx_) in (
+                ("3", W2, c3.in_channels, O2, W2 * O2, C3, C3, dy3, y3, y2, dzp3, dy2, O2),
+                ("2", W1, c2.in_channels, O1, W1 * O1, c2.out_channels, O2, dy2, y2, y1, dzp2, dy1, O1),
+                ("1", H, Lq, L1, Hp * L1, c1.out_channels, O1, dy1, y1, x1, dzp1, dx1, L1)):
+            gw, gb = grads[f"conv_{n}.0.weight"], grads[f"conv_{n}.0.bias"]
+            if batch is not None:           # dz (padded) + the input gradient now; the weight / bias gradient joins the batch
+                ops.conv1d_selu_bwd(B, Wi, Ci, ldx_, xbs, Co, ldo_, k, dy_, y_, x_, P[f"c{n}_wq"], dzp_, None, None, dx_, lddx_, x3=x3)
+                batch.add_conv_dw(B, Wi, Ci, ldx_, xbs, Co, ldo_, k, dzp_, x_, W(f"dwp{n}", (Co, k * ldx_)), gw, gb, x3=x3)
+            else:
+                ops.conv1d_selu_bwd(B, Wi, Ci, ldx_, xbs, Co, ldo_, k, dy_, y_, x_, P[f"c{n}_wq"], dzp_, gw, gb, dx_, lddx_, x3=x3)
         dhs = W("dhs", (Lq, B, H))
         ops.cast_transpose(dx1, B * H, Lq, dstT=dhs.view(Lq, B * H), lds=L1)          # dhs[t][b][w] = dx1[(b, w)][t]
         # K2 backward (reverse wavefront) + weight gradients
@@ -637,10 +663,21 @@ class _EncoderFn(torch.autograd.Function):
         fork.run_deferred(1)      # the decoder's remaining weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
         ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, Hp, cs, gates,
                     dG, dstate, tag="enc_lstm_bwd", poison=L.grad_poison(params))
-        _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp)
+        _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp, batch=batch)
         # K1 backward: table gradient, then embedding / W_ih0
         dtbl = W("dtbl", (Cv, G4))
-        ops.scatter_rows_tb(idx, dG[0], dtbl, B, Lq, Cv, G4)
+        if batch is not None:
+            # dtbl[v] = sum of dG0[t, b] over the positions holding token v = onehot(idx)^T . dG0: one more problem of the batch (exact-f32 sums in
+            # a fixed order).  The one-hot rows follow idx's own order (row b * L + t); the matching row of dG0 [T, B, 4H] is reached through the
+            # B operand's row groups (group = L, stride between groups = one batch row, stride inside = one time step).
+            oh = W("idx_onehot", (B * Lq, _pad(Cv, 4)))
+            ops.onehot_f32(idx, oh, Cv)
+            batch.add(oh, dG[0], dtbl, Cv, G4, B * Lq, lda=oh.stride(0), ldb=B * G4, b_group=Lq, b_gstride=G4)
+            batch.run()
+            for l in range(NL):
+                grads[f"gru.bias_hh_l{l}"].copy_(grads[f"gru.bias_ih_l{l}"])
+        else:
+            ops.scatter_rows_tb(idx, dG[0], dtbl, B, Lq, Cv, G4)
         ops.gemm_nt(dtbl, P["Wih0T"], grads["embedding.weight"], Cv, E, G4)
         Cp = _pad(Cv, 4)
         dtblT = W("dtblT", (G4, Cp))
@@ -835,7 +872,10 @@ class _DecoderFn(torch.autograd.Function):
         # instead of two (at the per-rank batch of a DP job the 128-tile launches cost little: K = T * b is short).
         gsync = getattr(sink[0], "grad_sync", None) if sink is not None else None
         dp_early = gsync is not None and gsync.active and gsync.allow_early
-        nlow = min(int(L.knob("MVAE_DEFER_LAYERS", "2")), NL - 1)
+        # two parts (upper layers + head, lower layers) where the peer releases them at two points of its backward; ONE part at the small per-GPU
+        # batches whose GEMMs are released at once on a capped grid (round 5, b = 128: 5.50 -> 5.37 ms per step with 160 workgroups -- the gap
+        # between two grouped launches, ~0.1 ms of bias / column-sum launches, closes, and the main stream keeps 96 compute units)
+        nlow = min(int(L.knob("MVAE_DEFER_LAYERS", "0" if TB <= int(L.knob("MVAE_WGRAD_LATE_TB", 32768)) else "2")), NL - 1)
         per_layer = L.knob("MVAE_WGRAD_PER_LAYER", "1" if dp_early else "0") == "1"
         if per_layer:
             parts = [[l] for l in range(NL - 1, -1, -1)]

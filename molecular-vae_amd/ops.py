@@ -249,6 +249,53 @@ def gemm_tn_grouped(problems, max_workgroups=0):
     check(lib.mvae_gemm_tn_grouped_capped(n, arr, int(max_workgroups), ptr(ws), need, stream_ptr()), "mvae_gemm_tn_grouped_capped")
 
 
+class TnF32Batch:
+    """Collects exact-f32 (or 3 x bf16) TN contractions that only feed the optimiser -- the parameter gradients of an encoder's backward pass --
+    and runs them as ONE launch + ONE split-K reduction (mvae_gemm_tn_f32_multi) instead of a dozen half-empty ones.  Operands must stay alive
+    and unchanged until run(); run() of more than MVAE_TN_F32_MULTI_MAX problems issues several launches."""
+    MAX = 16
+
+    def __init__(self, device):
+        self.device, self.probs, self.keep, self.after = device, [], [], []
+
+    def add(self, A, B, out, M, N, K, lda=None, ldb=None, ldc=None, colsum_out=None, colsum_accumulate=False, accumulate=False, x3=False,
+            b_group=0, b_gstride=0):
+        """out[M, N] (+)= A[:K, :M]^T . B[:K, :N]; colsum_out[m] (+)= sum_k A[k, m].  b_group > 0: row r of B starts at element
+        (r // b_group) * b_gstride + (r % b_group) * ldb (a permuted view of a [T, B, W] buffer, see MolEncoder's table gradient)."""
+        assert A.dtype == B.dtype == out.dtype == torch.float32
+        q = L.GemmTnF32Problem()
+        q.M, q.N, q.K = M, N, K
+        q.A, q.lda, q.a_group, q.a_gstride = A.data_ptr(), (A.stride(0) if lda is None else lda), 0, 0
+        q.B, q.ldb, q.b_group, q.b_gstride = B.data_ptr(), (B.stride(0) if ldb is None else ldb), b_group, b_gstride
+        q.C, q.ldc, q.accumulate = out.data_ptr(), (out.stride(0) if ldc is None else ldc), 1 if accumulate else 0
+        q.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
+        q.colsum_accumulate, q.x3 = (1 if colsum_accumulate else 0), (1 if x3 else 0)
+        self.probs.append(q)
+        self.keep += [A, B, out, colsum_out]
+
+    def add_conv_dw(self, B, W, Cin, ldx, x_bs, Cout, ldo, k, dzp, x, dwp, dw, db, x3=False):
+        """The weight / bias gradient of a channels-last Conv1d whose mvae_conv1d_act_bwd call skipped it (dw = None): dwp is the packed
+        scratch [Cout, k * ldx]; after run() it is unpacked into the parameter layout dw [Cout, Cin, k]."""
+        q = L.GemmTnF32Problem()
+        check(L.load().mvae_conv1d_dw_problem(B, W, Cin, ldx, x_bs, Cout, ldo, k, ptr(dzp), ptr(x), ptr(dwp), ptr(db), 1 if x3 else 0, C.byref(q)),
+              "mvae_conv1d_dw_problem")
+        self.probs.append(q)
+        self.keep += [dzp, x, dwp, db, dw]
+        self.after.append(lambda: check(L.load().mvae_conv1d_unpack_dw(Cin, Cout, k, ptr(dwp), ldx, ptr(dw), stream_ptr()), "mvae_conv1d_unpack_dw"))
+
+    def run(self):
+        lib = L.load()
+        for i in range(0, len(self.probs), self.MAX):
+            part = self.probs[i:i + self.MAX]
+            arr = (L.GemmTnF32Problem * len(part))(*part)
+            need = lib.mvae_gemm_tn_f32_multi_workspace(len(part), arr)
+            ws = Scratch.get(need, self.device, tag="tn_f32_multi") if need else None
+            check(lib.mvae_gemm_tn_f32_multi(len(part), arr, ptr(ws), need, stream_ptr()), "mvae_gemm_tn_f32_multi")
+        for fn in self.after:
+            fn()
+        self.probs, self.keep, self.after = [], [], []
+
+
 def colsum_t(X, M, N, out, ldx=None):
     lib = L.load()
     need = lib.mvae_colsum_t_workspace(M, N)
@@ -335,6 +382,11 @@ def onehot_tb(idx, out, B, Lq, nrows):
     """out[(t*B + b), c] = (idx[b, t] == c) for c < ld (bf16, time-major rows): the K-major operand that turns the table scatter
     dtable = sum_rows onehot^T . d into one TN GEMM."""
     check(L.load().mvae_onehot_tb(ptr(idx), B, Lq, nrows, ptr(out), out.stride(0), stream_ptr()), "mvae_onehot_tb")
+
+
+def onehot_f32(idx, out, nrows):
+    """out[r, c] = (idx.flat[r] == c), fp32, rows in idx's own order."""
+    check(L.load().mvae_onehot_f32(ptr(idx), idx.numel(), nrows, ptr(out), out.stride(0), stream_ptr()), "mvae_onehot_f32")
 
 
 def gather_rows_tb(idx, table, out, B, Lq, nrows, W, base=None):
@@ -446,7 +498,8 @@ def conv1d_selu_fwd(x, B, W, ldx, x_bs, Cout, k, wp, bias, y, ldy, act=L.ACT_SEL
 
 
 def conv1d_selu_bwd(B, W, Cin, ldx, x_bs, Cout, ldo, k, dy, y, x, wq, dzp, dw, db, dx, lddx, act=L.ACT_SELU, x3=False):
-    """x3: the input-gradient GEMM multiplies its fp32 operands as 3 x bf16 products (MVAE_CONV_BWD_X3: gradients of the bf16 training mode)."""
+    """x3: the input-gradient GEMM multiplies its fp32 operands as 3 x bf16 products (MVAE_CONV_BWD_X3: gradients of the bf16 training mode).
+    dw None: only dzp and dx are produced (the weight gradient joins a TnF32Batch: add_conv_dw)."""
     lib = L.load()
     if x3:
         act = act | L.CONV_BWD_X3
@@ -621,6 +674,20 @@ def persist_check(sync=False):
     return found
 
 
+_STATUS_RING = {"buf": None, "n": 0}
+
+
+def _status_slot():
+    """One int32[4] slot of a pinned ring allocated ONCE (a fresh pinned allocation per launch is a hipHostMalloc per launch, and that call
+    waits for the device: with a 1.4 ms persistent kernel in flight it kept the host from enqueueing the launches behind it).  512 slots:
+    persist_check() retires completed records at every call, so a slot is long done when the ring comes round."""
+    r = _STATUS_RING
+    if r["buf"] is None:
+        r["buf"] = torch.zeros(512, 4, dtype=torch.int32).pin_memory()
+    r["n"] += 1
+    return r["buf"][r["n"] % 512]
+
+
 def _status_view(addr, bufs):
     """int32[4] view of the status record at device address `addr`, which lies inside one of the scratch tensors `bufs`."""
     for b in bufs:
@@ -634,7 +701,7 @@ def _after_spin_launch(what, addr, bufs, poison, rerun):
     """A launch with bounded spins was enqueued; its status record is at `addr`.  poison given: asynchronous bookkeeping only.  Otherwise wait
     for the record and run `rerun()` (the same pass with no_spin set) if the launch gave up."""
     rec = _status_view(addr, bufs)
-    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+    host = _status_slot()
     host.copy_(rec, non_blocking=True)
     ev = torch.cuda.Event(); ev.record()
     if poison is not None:

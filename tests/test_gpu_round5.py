@@ -273,3 +273,65 @@ def test_no_status_is_read_where_no_spinning_kernel_ran():
     worst = max(gh.grad_report(out["grads"], ref["grads"]).values())
     assert worst < 1e-3, worst
     assert ops.PERSIST_STATS["failures"] == 0
+
+
+# ---------------------------------------------------------------------------------------------- the encoder's parameter-gradient GEMMs in one launch
+def test_tn_f32_multi_launch_vs_float64_and_the_single_launches():
+    """mvae_gemm_tn_f32_multi: problems of different shapes (the encoder's heads / dense / LSTM(72) weight gradients at b = 128, a tiny one, one
+    that accumulates, one in the 3 x bf16 form) in ONE launch against numpy float64 -- exact-f32 products: 2e-6 relative; x3: 5e-5 -- and
+    against the same contractions launched one by one (bit-equal column sums are not required: the split over K differs)."""
+    rs = np.random.RandomState(0)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    shapes = [(292, 512, 128, True, False, False), (512, 1344, 128, True, False, False), (288, 72, 15360 - 128, False, False, False),
+              (288, 72, 15360, True, False, False), (288, 4, 15360, True, False, False), (35, 288, 700, False, True, False),
+              (64, 2304, 2688, True, False, True), (5, 3, 9, False, False, False)]
+    batch, want, outs = ops.TnF32Batch(dev), [], []
+    for (M, N, K, cs, acc, x3) in shapes:
+        lda, ldb = (M + 3) // 4 * 4 + 4, (N + 3) // 4 * 4 + 8
+        A = np.zeros((K, lda)); A[:, :M] = rs.standard_normal((K, M))
+        Bm = np.zeros((K, ldb)); Bm[:, :N] = rs.standard_normal((K, N))
+        c0 = rs.standard_normal((M, N)) if acc else np.zeros((M, N))
+        out, csum = t(c0), (torch.full((M,), 7.0, device=dev) if cs else None)
+        batch.add(t(A), t(Bm), out, M, N, K, lda=lda, ldb=ldb, colsum_out=csum, accumulate=acc, x3=x3)
+        want.append((c0 + A[:, :M].T @ Bm[:, :N], A[:, :M].sum(0), 5e-5 if x3 else 2e-6))
+        outs.append((out, csum))
+    batch.run()
+    torch.cuda.synchronize()
+    for (out, csum), (w, wcs, tol), sh in zip(outs, want, shapes):
+        assert rel(out.cpu().numpy(), w) < tol, sh
+        if csum is not None:
+            assert rel(csum.cpu().numpy(), wcs) < tol, sh
+    # more problems than one launch takes: split into several launches
+    many = ops.TnF32Batch(dev)
+    res = []
+    for i in range(ops.TnF32Batch.MAX + 3):
+        A, Bm = rs.standard_normal((40 + i, 8)), rs.standard_normal((40 + i, 12))
+        o_ = torch.zeros(8, 12, device=dev)
+        many.add(t(A), t(Bm), o_, 8, 12, 40 + i); res.append((o_, A.T @ Bm))
+    many.run()
+    for o_, w in res:
+        assert rel(o_.cpu().numpy(), w) < 2e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-4)])
+def test_encoder_parameter_gradients_batched_equal_the_one_by_one_launches(dtype, tol, monkeypatch):
+    """MolEncoder backward with every parameter-gradient GEMM in ONE mvae_gemm_tn_f32_multi launch (the default) against MVAE_ENC_DW_BATCH=0 (one
+    launch each, where autograd would put it): every encoder gradient agrees to fp32 summation order (bf16 mode: the conv gradients use 3 x bf16
+    products in both forms); b = 128 and a ragged batch."""
+    for B in (128, 37):
+        torch.manual_seed(5)
+        model = mv.MolecularVAE(dtype=dtype).to(dev)
+        lf = mv.make_loss_function(120)
+        idx = torch.randint(0, 35, (B, 120), generator=torch.Generator().manual_seed(B)).to(dev)
+        ohe = torch.nn.functional.one_hot(idx, 35).float()
+        eps = (1e-2 * torch.randn(B, 292, generator=torch.Generator().manual_seed(1))).to(dev)
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MVAE_ENC_DW_BATCH", mode)
+            model.zero_grad(set_to_none=True)
+            recon, mu, lv = model(idx, eps=eps)
+            lf(recon, ohe, mu, lv).backward()
+            torch.cuda.synchronize()
+            got[mode] = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.encoder.named_parameters()}
+        bad = {k: rel(got["1"][k], got["0"][k]) for k in got["1"] if rel(got["1"][k], got["0"][k]) > tol}
+        assert not bad, (B, bad)

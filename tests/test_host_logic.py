@@ -132,11 +132,13 @@ def test_forward_backward_bookkeeping_with_stubbed_kernels(monkeypatch):
         def f(*a, **k):
             calls.append(name)
         return f
-    for name in ("gemm_nt", "gemm_tn", "gemm_tn_f32_colsum", "colsum_t", "cast_transpose", "permute021", "gather_rows_tb", "scatter_rows_tb", "rowsum", "timesum", "colsum",
+    for name in ("gemm_nt", "gemm_tn", "gemm_tn_f32_colsum", "colsum_t", "cast_transpose", "permute021", "gather_rows_tb", "scatter_rows_tb", "onehot_f32", "rowsum", "timesum", "colsum",
                  "selu_bwd", "conv1d_pack_weights", "conv1d_selu_fwd", "conv1d_selu_bwd", "lambda_fwd", "lambda_bwd", "softmax_tb_fwd", "softmax_tb_bwd",
                  "rnn_fwd", "rnn_bwd"):
         monkeypatch.setattr(ops, name, stub(name))
     monkeypatch.setattr(ops.PackList, "run", lambda self: calls.append("pack_multi"))      # the multi-tensor pack launch
+    monkeypatch.setattr(ops.TnF32Batch, "run", lambda self: calls.append(f"tn_f32_multi[{len(self.probs)}]"))       # the encoder's parameter-gradient GEMMs: ONE launch
+    monkeypatch.setattr(ops.TnF32Batch, "add_conv_dw", lambda self, *a, **k: self.probs.append("conv"))
     monkeypatch.setattr(M, "_require_cuda", lambda dev, what: None)
     enc = mv.MolEncoder(i=24, o=16, c=12, h_size=56, num_lstm=2)
     dec = mv.MolDecoder(i=16, o=24, c=12, num_gru=2, h_size=32, dtype=torch.float32)
@@ -148,6 +150,8 @@ def test_forward_backward_bookkeeping_with_stubbed_kernels(monkeypatch):
     for p in list(enc.parameters()) + list(dec.parameters()):
         assert p.grad is not None and p.grad.shape == p.shape
     assert calls.count("rnn_fwd") == 2 and calls.count("rnn_bwd") == 2 and calls.count("conv1d_selu_bwd") == 3
+    # heads (2) + dense_1 + 3 convolutions + LSTM(2 layers): dW_hh x 2, dW_ih of layer 1, the layer-0 bias product -- all in the one batch
+    assert calls.count("tn_f32_multi[11]") == 1                     # ... and the token-table gradient
     assert calls.count("pack_multi") == 2 and len(enc._pack_list.jobs) >= 10 and len(dec._pack_list.jobs) >= 8     # one pack launch per module
     # a second forward invalidates the saved workspace of the first
     z2, _, _ = enc(idx, torch.zeros(3, 16))
