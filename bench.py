@@ -328,11 +328,24 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    ops.persist_check(sync=True)              # a persistent dataflow launch that gave up would have left garbage: never report such a run
+    # launches with bounded spins that gave up (ops.PERSIST_DEFAULT): the optimiser skipped those steps on the device -- the run stays valid but
+    # the line says so, per rank (a rank that fell back to the wavefront schedules explains a slow SCALE point)
+    ops.persist_check(sync=True)
+    sched = dict(persist_fwd=ops.PERSIST_STATS["launches"], persist_bwd=ops.PERSIST_STATS["bwd_launches"], rowres_pipe=ops.PERSIST_STATS["rowres_pipe"],
+                 failures=ops.PERSIST_STATS["failures"], disabled=bool(ops.PERSIST_STATS["disabled"]),
+                 skipped_steps=int(float(getattr(wl, "optimizer", None).skipped_steps)) if hasattr(getattr(wl, "optimizer", None), "skipped_steps") else 0)
+    rank_ms = [1e3 * dt / steps]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [1e3 * float(x) / steps for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        st = torch.tensor([sched["persist_fwd"], sched["persist_bwd"], sched["rowres_pipe"], sched["failures"], sched["skipped_steps"]], device=dev, dtype=torch.float64)
+        alls = [torch.zeros_like(st) for _ in range(world)]
+        dist.all_gather(alls, st)
+        sched["per_rank"] = [dict(zip(("persist_fwd", "persist_bwd", "rowres_pipe", "failures", "skipped_steps"), [int(v) for v in x.tolist()])) for x in alls]
     ms = 1e3 * dt / steps
     log(f"[{label}] timed region done: {ms:.2f} ms/step")
     tag_ms = {k: sum(s.elapsed_time(e) for s, e in v) / steps for k, v in prof.items()}      # per STEP (a tag may be recorded several times in one)
@@ -344,12 +357,14 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
         # overlap with backward did NOT hide.  MAX over ranks, like the step time.
         t = torch.tensor([tag_ms.get("dp_allreduce_exposed", 0.0)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        comm = dict(allreduce_exposed_ms=round(float(t), 3), form=("reduce-scatter + sharded clip/Adam + all-gather" if getattr(sync, "shard_optimizer", False) else
+        nst = max(1, steps + warmup)
+        comm = dict(allreduce_exposed_ms=round(float(t), 3), ms_per_step_min_over_ranks=round(min(rank_ms), 3), ms_per_step_max_over_ranks=round(max(rank_ms), 3),
+                    bytes_early_per_step=int(sync.stats["bytes_early"] / nst), bytes_rest_per_step=int(sync.stats["bytes_rest"] / nst), form=("reduce-scatter + sharded clip/Adam + all-gather" if getattr(sync, "shard_optimizer", False) else
                                                                   "all-reduce, early ranges from inside backward") + (", bf16 on the wire" if sync.compress else ""), world_size_reported=dist.get_world_size(), backend=dist.get_backend(),
                     gradient_bytes=4 * getattr(wl, "n_params", 0), early_ranges_per_step=(sync.stats["early_ranges"] / max(1, steps + warmup)) if sync else 0)
     roof["whole_step_tflops"] = round(wl.flops_per_step() * steps / dt / 1e12, 2)
     res = dict(value=round(B * world * steps / dt, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup, dtype=dtype,
-               final_loss=round(float(loss), 6), roofline=roof, config=wl.config(world), comm=comm)
+               final_loss=round(float(loss), 6), roofline=roof, config=wl.config(world), comm=comm, schedules=sched)
     if pipeline and hasattr(wl, "pipeline_steps"):
         pms = wl.pipeline_steps(max(5, steps // 2), 2)
         res["input_pipeline"] = dict(ms_per_step=round(pms, 3), value=round(B * world / (pms * 1e-3), 1), unit="molecules/s",
@@ -478,6 +493,7 @@ def main():
                data="synthetic", config=cfg, roofline=main_res["roofline"])
     if main_res.get("comm") is not None:
         out["comm"] = main_res["comm"]
+    out["schedules"] = main_res["schedules"]
     if main_res.get("input_pipeline") is not None:
         out["input_pipeline"] = main_res["input_pipeline"]
 

@@ -2,6 +2,7 @@
 // its deterministic scatter, SELU derivative, reparameterisation, softmax head, ELBO, reductions,
 // gradient-norm + Adam.  All reductions use fixed orders (wave shuffle -> LDS -> serial over blocks) so results
 // are bitwise reproducible run to run.
+#include <atomic>
 #include "common.hpp"
 #include "kernels.hpp"
 #include <stdlib.h>
@@ -1437,7 +1438,17 @@ int mvae_moses_sample_step(int dtype, int B, int V, int H, const void* h_top, in
   if (!h_top || !w_fc || !table || !base || !add_out || !x || !end_pads || !eos_mask || !w_out) return MVAE_ERR_INVALID;
   if (B < 1 || V < 1 || V > 64 || H < 1 || (W & 3) || W < 4 || !(temp > 0.f) || step < 0) return MVAE_ERR_INVALID;
   const size_t lds = (size_t)V * H * (dtype == MVAE_BF16 ? 2 : 4);
-  if (lds > 64 * 1024) return MVAE_ERR_UNSUPPORTED;
+  if (lds > 160 * 1024) return MVAE_ERR_UNSUPPORTED;                 // the head must fit the CU's LDS (fp32, H = 512: V <= 80; bf16: V <= 64 by the check above)
+  if (lds > 64 * 1024) {                                              // above the default dynamic-LDS limit: opt in (per device, like the persistent kernels)
+    static std::atomic<bool> attr[64];
+    int dev_id = 0;
+    MVAE_CHECK_HIP(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 64 || !attr[dev_id].load(std::memory_order_acquire)) {
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(moses_sample_step_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MVAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(moses_sample_step_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      if (dev_id >= 0 && dev_id < 64) attr[dev_id].store(true, std::memory_order_release);
+    }
+  }
   int blocks = (B + 3) / 4; if (blocks > 1024) blocks = 1024;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MVAE_BF16)

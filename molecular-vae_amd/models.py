@@ -502,6 +502,7 @@ class MolEncoder(nn.Module, _SavedState):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
+    @ops.traced("molvae_encoder_fwd")
     def forward(ctx, mod, idx, eps, *params):
         dev = idx.device
         _require_cuda(dev, "MolEncoder")
@@ -575,6 +576,7 @@ class _EncoderFn(torch.autograd.Function):
         return z, mu, logv
 
     @staticmethod
+    @ops.traced("molvae_encoder_bwd")
     def backward(ctx, dz, dmu, dlogv):
         mod, idx, eps = ctx.mod, ctx.idx, ctx.eps
         ws = mod._saved_ws(ctx.slot, ctx.gen, "MolEncoder")
@@ -768,6 +770,7 @@ class MolDecoder(nn.Module, _SavedState):
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
+    @ops.traced("molvae_decoder_fwd")
     def forward(ctx, mod, z, infer, *params):
         dev = z.device
         _require_cuda(dev, "MolDecoder")
@@ -808,6 +811,7 @@ class _DecoderFn(torch.autograd.Function):
         return recon
 
     @staticmethod
+    @ops.traced("molvae_decoder_bwd")
     def backward(ctx, drecon):
         mod, z = ctx.mod, ctx.z
         (recon,) = ctx.saved_tensors

@@ -73,6 +73,7 @@ class VAE(nn.Module, _SavedState):
         self.dp_group = None                 # process group of that reduction (None: the default group); moses_train_step sets it from the optimiser's GradSync
         self.last_drop_seed = None           # seed of the most recent train-mode forward (None: eval / injected mask)
         self.compute_dtype = dtype
+        self.prior = "zeros"                 # sample_z_prior: "zeros" = the reference as written (mosesvae.py:211), "normal" = N(0, I) as its docstring says
         self.noise = "device"                # reparameterisation noise: "device" = drawn by the library inside the latent launch; "torch" = torch.randn on the device generator
         self.__dict__["noise_stream"] = ops.NoiseStream()
         self._init_saved_state()
@@ -187,8 +188,12 @@ class VAE(nn.Module, _SavedState):
         recon, y, ntok = _MosesDecFn.apply(self, x_pad, len_t, z.to(self.device), drop, *params)
         return self._dp_token_mean(recon, ntok), x_pad, y
 
-    def sample_z_prior(self, n_batch):
-        """mosesvae.py:201-211 as intended (the reference reads an attribute it never sets): z ~ N(0, I)."""
+    def sample_z_prior(self, n_batch, normal=None):
+        """mosesvae.py:200-211.  The reference AS WRITTEN returns zeros (its randn line is commented out, :207-210) although its docstring says
+        z ~ N(0, I); a drop-in keeps that: `self.prior == "zeros"` (the default).  `normal=True` / `self.prior = "normal"` gives the documented
+        N(0, I) draw -- from the library's counter hash (noise == "device") or torch's device generator."""
+        if not (self.prior == "normal" if normal is None else normal):
+            return torch.zeros((n_batch, self.d_z), device=self.device)
         if self.noise == "device" and self.device.type == "cuda":
             seed, off = self.noise_stream.take(n_batch * self.d_z)
             return ops.normal_fill(torch.empty(n_batch, self.d_z, device=self.device), 1.0, seed, off)
@@ -622,6 +627,7 @@ class _MosesFn(torch.autograd.Function):
     """mosesvae.VAE.forward (mosesvae.py:126-140): both halves in ONE autograd node."""
 
     @staticmethod
+    @ops.traced("moses_step_fwd")
     def forward(ctx, mod, x_pad, lengths, eps, drop, *params):
         dev = x_pad.device
         _require_cuda(dev, "mosesvae.VAE")
@@ -637,6 +643,7 @@ class _MosesFn(torch.autograd.Function):
         return kl[0].clone(), recon, z, lv.clone(), y, ntok
 
     @staticmethod
+    @ops.traced("moses_step_bwd")
     def backward(ctx, dkl, drecon, dz_ext, dlv_ext, dy_ext, _dntok=None):
         mod, x_pad, lengths, eps, drop = ctx.mod, ctx.x_pad, ctx.lengths, ctx.eps, ctx.drop
         ws = mod._saved_ws(ctx.slot, ctx.gen, "mosesvae.VAE", "enc")
@@ -659,6 +666,7 @@ class _MosesEncFn(torch.autograd.Function):
     """mosesvae.VAE.forward_encoder (mosesvae.py:142-164): the encoder half ALONE -- no decoder kernel is launched."""
 
     @staticmethod
+    @ops.traced("moses_encoder_fwd")
     def forward(ctx, mod, x_pad, lengths, eps, *params):
         dev = x_pad.device
         _require_cuda(dev, "mosesvae.VAE.forward_encoder")
@@ -670,6 +678,7 @@ class _MosesEncFn(torch.autograd.Function):
         return z, kl[0].clone(), lv.clone()
 
     @staticmethod
+    @ops.traced("moses_encoder_bwd")
     def backward(ctx, dz_ext, dkl, dlv_ext):
         mod, x_pad, lengths, eps = ctx.mod, ctx.x_pad, ctx.lengths, ctx.eps
         ws = mod._saved_ws(ctx.slot, ctx.gen, "mosesvae.VAE.forward_encoder", "enc")
@@ -688,6 +697,7 @@ class _MosesDecFn(torch.autograd.Function):
     """mosesvae.VAE.forward_decoder (mosesvae.py:166-199): teacher-forced decoder on a latent the caller supplies; differentiable in z."""
 
     @staticmethod
+    @ops.traced("moses_decoder_fwd")
     def forward(ctx, mod, x_pad, lengths, z, drop, *params):
         dev = x_pad.device
         _require_cuda(dev, "mosesvae.VAE.forward_decoder")
@@ -701,6 +711,7 @@ class _MosesDecFn(torch.autograd.Function):
         return recon, y, ntok
 
     @staticmethod
+    @ops.traced("moses_decoder_bwd")
     def backward(ctx, drecon, dy_ext, _dntok=None):
         mod, x_pad, lengths, drop = ctx.mod, ctx.x_pad, ctx.lengths, ctx.drop
         ws = mod._saved_ws(ctx.dslot, ctx.dgen, "mosesvae.VAE.forward_decoder", "dec")

@@ -20,11 +20,69 @@ def _pad(n, m):
 PROFILE = None
 
 
+# roctx ranges (tracing): with MVAE_ROCTX=1 in the environment (or ops.enable_roctx()) every tagged launch group and every phase
+# of the step (encoder / decoder forward and backward, the optimiser, the MOSES halves) is bracketed by roctxRangePush / Pop, so that a
+# `rocprofv3 --kernel-trace --marker-trace` timeline groups the kernels by kernel family.  Off by default: two ctypes calls per range.
+_ROCTX = {"lib": None, "on": None}
+
+
+def enable_roctx(on=True):
+    if on and _ROCTX["lib"] is None:
+        for name in ("libroctx64.so", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/libroctx64.so"):
+            try:
+                lib = C.CDLL(name)
+                lib.roctxRangePushA.argtypes = [C.c_char_p]
+                _ROCTX["lib"] = lib
+                break
+            except OSError:
+                continue
+    _ROCTX["on"] = bool(on) and _ROCTX["lib"] is not None
+    return _ROCTX["on"]
+
+
+def _roctx_on():
+    if _ROCTX["on"] is None:
+        import os
+        enable_roctx(os.environ.get("MVAE_ROCTX", "0") not in ("", "0"))
+    return _ROCTX["on"]
+
+
+class trace_range:
+    """with ops.trace_range("dec_lstm_fwd"): ...   -- a named roctx range around the launches enqueued inside (no-op unless enabled)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.live = bool(self.name) and _roctx_on()
+        if self.live:
+            _ROCTX["lib"].roctxRangePushA(self.name.encode())
+        return self
+
+    def __exit__(self, *a):
+        if self.live:
+            _ROCTX["lib"].roctxRangePop()
+        return False
+
+
+def traced(name):
+    """Decorator form of trace_range (the autograd Functions' forward / backward)."""
+    def deco(fn):
+        def wrapper(*a, **k):
+            with trace_range(name):
+                return fn(*a, **k)
+        wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+        return wrapper
+    return deco
+
+
 class _Timed:
     def __init__(self, tag):
         self.tag = tag
+        self.range = trace_range(tag)
 
     def __enter__(self):
+        self.range.__enter__()
         if PROFILE is not None and self.tag:
             self.s = torch.cuda.Event(enable_timing=True); self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
@@ -34,6 +92,7 @@ class _Timed:
         if PROFILE is not None and self.tag:
             self.e.record()
             PROFILE.setdefault(self.tag, []).append((self.s, self.e))
+        self.range.__exit__()
         return False
 
 

