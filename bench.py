@@ -248,6 +248,9 @@ class MolVaeWorkload:
         d, o = leg[dom], leg[oth]
         traffic, src = pmc_traffic(d["pmc_key"], self.B, dtype)
         hbm_bound = dtype == "bf16" and d["floor_us"]["hbm"] > d["floor_us"]["mfma"]
+        # `bound` names the roof the headline fraction is taken against (MFMA: the unit BASELINE's north star asks for); `higher_floor` says which of
+        # the two floors of this launch is the binding one -- at B = 1024 the algorithmic bytes / 8 TB/s exceed the FLOPs / 2.5 PF/s, and
+        # frac_of_higher_floor is the fraction against THAT floor
         return dict(bound="mfma", kernel=d["kernel"], achieved=round(d["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(d["tflops"] / peak, 4),
                     floors_us=d["floor_us"], higher_floor=("hbm" if hbm_bound else "mfma"),
                     frac_of_higher_floor=round(max(d["floor_us"].values()) / d["us"], 4), algorithmic_bytes_per_launch=int(d["bytes"]),
@@ -270,20 +273,23 @@ class MolVaeWorkload:
 
 def pmc_traffic(kernel_key, B, dtype):
     """(HBM bytes per launch, source) of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, KB -> bytes).  NOT from this run: collected off-line with tests/collect_pmc.sh on a T = 16 micro-benchmark of
-    the same kernel at the same batch (bench.py cannot run the profiler on itself); (None, None) when no profile of this shape exists."""
+    correction + WRITE_SIZE, KB -> bytes).  NOT from this run: collected off-line with tests/collect_pmc.sh on a micro-benchmark of the same
+    kernel at the same batch (bench.py cannot run the profiler on itself) -- T = 120, the timed pass's own length, where such a profile exists
+    (the persistent kernels: a launch covers the whole pass and its traffic is reported per diagonal, like its time, so the fill / drain
+    diagonals weigh exactly as they do in the timed run), else T = 16; (None, None) when no profile of this shape exists."""
     if dtype != "bf16":
         return None, None
-    for name in (f"r04_pmc_kernels_T16_B{B}.json", f"r03_pmc_kernels_T16_B{B}.json", f"r02_pmc_kernels_T16_B{B}.json", f"r01_v9_pmc_kernels_T16_B{B}.json"):
+    for name, T_ in ((f"r05_pmc_kernels_T120_B{B}.json", 120), (f"r04_pmc_kernels_T16_B{B}.json", 16), (f"r03_pmc_kernels_T16_B{B}.json", 16),
+                     (f"r02_pmc_kernels_T16_B{B}.json", 16), (f"r01_v9_pmc_kernels_T16_B{B}.json", 16)):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
         for k, v in pm.items():
             if kernel_key in k and "hbm_read_MB_corrected" in v and "hbm_write_MB" in v:
-                # a persistent launch covers the whole pass: its traffic is reported per diagonal, like its time
                 return (int((v["hbm_read_MB_corrected"] + v["hbm_write_MB"]) * 1024 * 1024 / v.get("diagonals_per_launch", 1)),
-                        f"profiles/{name}: off-line PMC passes over a T=16 micro-benchmark of this kernel at B={B}, full-grid launches")
+                        f"profiles/{name}: off-line PMC passes over a T={T_} micro-benchmark of this kernel at B={B}"
+                        + (f", one launch = {v['diagonals_per_launch']} diagonals, traffic per diagonal" if "diagonals_per_launch" in v else ", full-grid launches"))
     return None, None
 
 
@@ -302,6 +308,7 @@ def measure(model, B, dtype, steps, warmup, dev, rank, world, sync, label, L=L_S
     import torch
     import torch.distributed as dist
     from molecular_vae_amd import ops
+    ops.PERSIST_STATS.update(launches=0, bwd_launches=0, rowres_pipe=0, failures=0, reruns=0)      # per measured configuration
     wl = make_workload(model, B, dtype, dev, rank, sync, L, C, noise=noise)
     log(f"[{label}] model built, per-GPU batch {B}, dtype {dtype}, world {world}")
     for i in range(warmup):
@@ -512,7 +519,8 @@ def main():
                                                    ("configs4_L256_C64_B2048", "molvae", 2048, "bf16", 5, 2, 256, 64)):
             r = measure(mdl, b, dt_, st, wu, dev, rank, 1, None, label, Lq, Cq)
             sec[label] = dict(value=r["value"], unit="molecules/s", ms_per_step=r["ms_per_step"], steps=st, warmup=wu, dtype=dt_,
-                              per_gpu_batch=b, final_loss=r["final_loss"], roofline=r["roofline"], workload=r["config"]["workload"])
+                              per_gpu_batch=b, final_loss=r["final_loss"], roofline=r["roofline"], workload=r["config"]["workload"],
+                              schedules=r["schedules"])
         sec["generation_from_latent_b2000"] = measure_generation(dev)
         sec["moses_sample_b1024"] = measure_moses_sample(dev)
         out["secondary"] = sec
