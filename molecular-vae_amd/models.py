@@ -240,6 +240,7 @@ def _params_key(params):
 
 
 DW_KSPLIT = "1"      # K-chunks of the grouped decoder weight-gradient launches (see _lstm_weight_grads)
+WGRAD_CAPS_BIG = "0:0"   # workgroup caps of the two parts of the large-batch schedule (0: one workgroup per tile)
 WGRAD_CAP = "160"      # workgroups of the grouped weight-gradient launches at small per-GPU batches (0: one per tile, released next to the encoder LSTM backward)
 
 
@@ -612,7 +613,9 @@ class _EncoderFn(torch.autograd.Function):
         # left on the way are the input-gradient chain.  MVAE_ENC_DW_BATCH=0: one launch each, where it stands (A/B, tests).
         # (measured, ms per step: b = 128 5.47 -> 5.35, B = 512 17.14 -> 16.99; B = 1024 28.28 -> 28.66 -- there each of these GEMMs is big enough to
         # fill its launch and, issued where it stands, runs under the decoder's weight-gradient launches instead of behind the LSTM backward)
-        batch = ops.TnF32Batch(dev) if L.knob("MVAE_ENC_DW_BATCH", "1" if B * Lq <= 65536 else "0") != "0" else None
+        bmode = L.knob("MVAE_ENC_DW_BATCH", "1" if B * Lq <= 65536 else "0")      # "2": only the LSTM stack's products + the table gradient (the tail)
+        lstm_batch = ops.TnF32Batch(dev) if bmode != "0" else None
+        batch = lstm_batch if bmode == "1" else None
         for k, nm in enumerate(("lmbd.z_mean", "lmbd.z_log_var")):
             if batch is not None:
                 batch.add(dmulv[:, k * o:(k + 1) * o], d, grads[nm + ".weight"], o, 512, B, lda=2 * o, ldb=512, colsum_out=grads[nm + ".bias"])
@@ -667,6 +670,7 @@ class _EncoderFn(torch.autograd.Function):
         fork.run_deferred(1)      # the decoder's remaining weight-gradient GEMMs: they fill the CUs the row-resident backward leaves idle
         ops.rnn_bwd(L.CELL_LSTM, f32, Lq, B, H, P["WhhT"], [G4] * NL, P["WihT"], [G4] * NL, dhs, H, hs, Hp, cs, gates,
                     dG, dstate, tag="enc_lstm_bwd", poison=L.grad_poison(params))
+        batch = lstm_batch
         _lstm_weight_grads(ws, grads, "gru", f32, dev, NL, Lq, B, H, dG, G4, hs, Hp, batch=batch)
         # K1 backward: table gradient, then embedding / W_ih0
         dtbl = W("dtbl", (Cv, G4))
@@ -906,7 +910,9 @@ class _DecoderFn(torch.autograd.Function):
                         ops.gemm_nt(dlT, hsT, grads["decoded_mean.module.0.weight"], Cv, H, TB, lda=ldT, ldb=ldT)
                         ops.rowsum(dlT, Cv, TB, grads["decoded_mean.module.0.bias"])
                 layers = range(NL) if k is None else parts[k]
-                _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers, max_workgroups=wg_cap[0])
+                caps_big = [int(c) for c in L.knob("MVAE_WGRAD_CAPS", WGRAD_CAPS_BIG).split(":")]       # per part, the two-part schedule of large batches
+                mw = wg_cap[0] if (wg_cap[0] or k is None) else caps_big[min(k, len(caps_big) - 1)]
+                _lstm_weight_grads(ws, grads, "gru", dt, dev, NL, Lq, B, H, dG, ldg, hs, ldh, layers=layers, max_workgroups=mw)
                 if k is not None and dp_early:
                     # What this part produced is final on this stream: all-reduce it now -- [first parameter of its lowest layer, start of
                     # the previous part) (part 0: to the end of our range, i.e. with the head).  weight_ih_l0 / latent_input, produced on
