@@ -24,6 +24,8 @@ ap.add_argument("--model", default="molvae", choices=["molvae", "moses"])
 ap.add_argument("--shard", action="store_true", help="world > 1: reduce-scatter + sharded clip / Adam + all-gather (FusedAdam(shard_optimizer=True))")
 ap.add_argument("--compress", default=None, choices=[None, "bf16"], help="world > 1: gradient all-reduce as bfloat16")
 ap.add_argument("--backend", default="gloo", help="gloo (ranks sharing the GPU) or nccl (= RCCL; one rank per GPU)")
+ap.add_argument("--poison-rank", type=int, default=-1, help="this rank's persistent launches give up (MVAE_PERSIST_SPIN=1) at --poison-step: every rank must skip that update")
+ap.add_argument("--poison-step", type=int, default=1)
 ap.add_argument("--force-comm", action="store_true", help="ONE rank: initialise a one-rank process group on --backend and issue every collective anyway (GradSync(force=True))")
 args = ap.parse_args()
 if args.compare:
@@ -101,6 +103,11 @@ ohe = torch.nn.functional.one_hot(data, VOCAB).float()
 out = dict(loss=[], psum=[], gnorm=[], world=world)
 for s in range(args.steps):
     eps = eps_all[s, sl].to(dev)
+    if args.poison_rank == rank:
+        if s == args.poison_step:
+            os.environ["MVAE_TUNING"] = "1"; os.environ["MVAE_PERSIST_SPIN"] = "1"
+        else:
+            os.environ.pop("MVAE_PERSIST_SPIN", None)
     opt.zero_grad(set_to_none=True)
     recon, mu, lv = model(data, eps=eps)
     loss = loss_fn(recon, ohe, mu, lv)
@@ -114,6 +121,19 @@ for s in range(args.steps):
     out["psum"].append(float(sum(p.detach().abs().sum() for p in model.parameters())))
 out["early_ranges"] = sync.stats["early_ranges"] if sync is not None else 0
 out["buckets"] = sync.stats["buckets"] if sync is not None else 0
+if args.poison_rank >= 0:
+    import warnings
+    from molecular_vae_amd import ops as _ops
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _ops.persist_check(sync=True)
+    mine = dict(psum=out["psum"], skipped=float(opt.skipped_steps), failures=_ops.PERSIST_STATS["failures"], persist=_ops.PERSIST_STATS["launches"] + _ops.PERSIST_STATS["bwd_launches"])
+    allr = [None] * world
+    if world > 1:
+        dist.all_gather_object(allr, mine)
+    else:
+        allr = [mine]
+    out["ranks"] = allr
 out["pcheck"] = [float(p.detach().double().sum()) for p in list(model.parameters())[:6]] + [float(opt.state[next(iter(model.decoder.gru.parameters()))]["exp_avg"].double().abs().sum())]
 if args.shard and (world > 1 or force):
     # a state_dict() taken now would hold stale moments for the other ranks' slices -- it must refuse until gather_state() ran

@@ -353,3 +353,30 @@ def test_f32_model_samples_with_a_vocabulary_above_32_tokens():
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and len(a) == 16
     c, _ = model.sample(16, max_len=12, seed=6, return_tokens=True)
     assert any(not torch.equal(x, y) for x, y in zip(a, c))
+
+
+def test_two_ranks_skip_together_when_one_ranks_persistent_launch_gives_up(tmp_path):
+    """ADVICE r04 #1 / VERDICT r04 missing #3 in the data-parallel setting: two ranks (fresh child processes sharing this GPU, gloo), b = 128 each
+    in bf16 -- the shape of the persistent decoder passes.  At step 1 ONLY rank 1's persistent launches give up (poll budget 1): its poison slot
+    becomes NaN, the slot travels with the last gradient bucket, BOTH ranks' optimiser kernels skip the update (no rank raises, no rank is left
+    waiting in a collective), the parameters stay identical on both ranks through every step, step 1 leaves them untouched, step 2 trains."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = os.path.join(ROOT, "tests", "dp_equiv.py")
+    out = os.path.join(str(tmp_path), "poison.json")
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MVAE_PERSIST_SPIN"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), script, "--out", out, "--b", "128", "--steps", "3", "--dtype", "bf16", "--poison-rank", "1",
+                        "--poison-step", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    r0, r1 = res["ranks"]
+    assert r0["persist"] > 0 and r1["persist"] > 0                       # both ranks ran the persistent schedules
+    assert r1["failures"] >= 1 and r0["failures"] == 0                   # only rank 1's launches gave up ...
+    assert r0["skipped"] == 1.0 and r1["skipped"] == 1.0                 # ... and BOTH skipped exactly that one update
+    assert r0["psum"] == r1["psum"]                                      # the replicas never diverge
+    assert r0["psum"][1] == r0["psum"][0] and r0["psum"][2] != r0["psum"][1]
