@@ -493,15 +493,25 @@ def _dec_backward(mod, ws, P, grads, x_pad, lengths, drop, drecon, dy_ext, dz_ex
             grads[f"decoder_rnn.bias_hh_l{l}"][:2 * Hd].copy_(s4[:2 * Hd]); grads[f"decoder_rnn.bias_hh_l{l}"][2 * Hd:].copy_(s4[3 * Hd:])
 
     def dec_weight_grads():
+        # the 3 x (dW_hh[r, z], dW_hh[n], dW_ih) contractions of the stack, one split-K TN GEMM each.  MVAE_MOSES_DW_GROUPED=1: ONE grouped launch of
+        # full-K 256 x 256 tiles instead (8 problems, 66 tiles) -- measured in round 5 and NOT kept: 5.46 vs 5.18 ms per step at B = 1024 (66
+        # workgroups with K = 62 k each run longer than the whole tail they sit beside; the chip-wide split-K launches finish sooner)
+        probs = []
         for l in range(NL):
             a = dG_d[l].view(TB, ldg_d)
             hprev = hsx_d[l][:T].reshape(TB, ldh_d)                  # h_{t-1} for every t (slot 0 = h_0)
             gw = grads[f"decoder_rnn.weight_hh_l{l}"]
-            _kmajor_gemm(ws, "dwhh_rz", a, ldg_d, 2 * Hd, hprev, ldh_d, Hd, TB, gw[:2 * Hd], dev)
-            _kmajor_gemm(ws, "dwhh_n", a[:, 3 * Hd:], ldg_d, Hd, hprev, ldh_d, Hd, TB, gw[2 * Hd:], dev)
+            probs.append(dict(A=a, B=hprev, out=gw[:2 * Hd], M=2 * Hd, N=Hd, K=TB, lda=ldg_d, ldb=ldh_d, tag="dwhh_rz"))
+            probs.append(dict(A=a[:, 3 * Hd:], B=hprev, out=gw[2 * Hd:], M=Hd, N=Hd, K=TB, lda=ldg_d, ldb=ldh_d, tag="dwhh_n"))
             if l > 0:                                                 # the layer's input: the output of layer l-1 (after its dropout in train mode)
                 xin = hd[l - 1].view(TB, ldh_d) if hd is not None else hsx_d[l - 1][1:].reshape(TB, ldh_d)
-                _kmajor_gemm(ws, "dwih", a, ldg_d, 3 * Hd, xin, ldh_d, Hd, TB, grads[f"decoder_rnn.weight_ih_l{l}"], dev)
+                probs.append(dict(A=a, B=xin, out=grads[f"decoder_rnn.weight_ih_l{l}"], M=3 * Hd, N=Hd, K=TB, lda=ldg_d, ldb=ldh_d, tag="dwih"))
+        if (L.knob("MVAE_MOSES_DW_GROUPED", "0") != "0" and dt == torch.bfloat16
+                and all(ops.gemm_tn_grouped_supported(q["A"], q["M"], q["N"], q["K"], q["lda"], q["ldb"]) for q in probs)):
+            ops.gemm_tn_grouped(probs)
+        else:
+            for q in probs:
+                _kmajor_gemm(ws, q["tag"], q["A"], q["lda"], q["M"], q["B"], q["ldb"], q["N"], q["K"], q["out"], dev)
         # layer-0 input = [emb(x_t), z]: table gradient for the embedding part (the z part is on the path to the encoder: main stream)
         dtbl3 = W("dec_dtbl3", (V, 3 * Hd))
         if onehot is not None:
