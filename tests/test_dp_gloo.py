@@ -142,6 +142,13 @@ def _worker8(rank, world, port, out_dir):
     part[rank * cps:(rank + 1) * cps] = (mine.double() ** 2).view(cps, 65536).sum(1).float()
     dist.all_reduce(part)
     assert not bool(torch.isfinite(part.sum())), "every rank sees the poisoned norm and skips the update"
+    # (c) the reparameterisation noise streams of the ranks: same torch.manual_seed everywhere, different device-noise seeds (the rank is folded in)
+    torch.manual_seed(42)
+    from molecular_vae_amd import ops
+    seed = ops.NoiseStream().take(1)[0]
+    seeds = [None] * world
+    dist.all_gather_object(seeds, seed)
+    assert len(set(seeds)) == world, seeds
     if rank == 0:
         np.save(os.path.join(out_dir, "ok8.npy"), np.array([1.0]))
     dist.barrier()
