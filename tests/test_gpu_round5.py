@@ -380,3 +380,4 @@ def test_two_ranks_skip_together_when_one_ranks_persistent_launch_gives_up(tmp_p
     assert r0["skipped"] == 1.0 and r1["skipped"] == 1.0                 # ... and BOTH skipped exactly that one update
     assert r0["psum"] == r1["psum"]                                      # the replicas never diverge
     assert r0["psum"][1] == r0["psum"][0] and r0["psum"][2] != r0["psum"][1]
+
