@@ -442,10 +442,11 @@ int rnn_persist_fwd(const mvae_rnn_fwd_desc* d, void* ws, size_t ws_bytes, hipSt
 #ifdef MVAE_TUNING
   a.dbg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + 64 + (size_t)PNL * d->T * 64 * 4);
 #endif
-  // ~1 s of polling rounds: far beyond any step, short enough that a stuck launch ends.  MVAE_PERSIST_SPIN (tests: 1 = give up at the first
+  // ~0.2 s of polling rounds (2^17 x ~1.6 us): far beyond any step or any wait for a compute unit, short enough that a launch that cannot
+  // make progress costs a fifth of a second, not two (round 5: a failure is survived, so the price of one is what matters).  MVAE_PERSIST_SPIN (tests: 1 = give up at the first
   // flag that is not there yet, which exercises the failure path) and MVAE_PERSIST_SAFE are honoured under MVAE_TUNING=1 only.
   const char* sp = mvae_knob("MVAE_PERSIST_SPIN");
-  a.spin_limit = sp ? (uint32_t)atoi(sp) : (1u << 20);
+  a.spin_limit = sp ? (uint32_t)atoi(sp) : (1u << 17);
   const char* sf = mvae_knob("MVAE_PERSIST_SAFE");
   a.safe = (sf && atoi(sf) != 0) ? 1 : 0;
   // the 160 KB dynamic-LDS opt-in is a per-DEVICE function attribute: once per device, not once per process

@@ -480,7 +480,7 @@ int rnn_persist_bwd(const mvae_rnn_bwd_desc* d, void* ws, size_t ws_bytes, hipSt
   a.dbg = reinterpret_cast<unsigned long long*>(w + head + EXCH_BYTES);
 #endif
   const char* sp = mvae_knob("MVAE_PERSIST_SPIN");
-  a.spin_limit = sp ? (uint32_t)atoi(sp) : (1u << 20);
+  a.spin_limit = sp ? (uint32_t)atoi(sp) : (1u << 17);
   const char* sf = mvae_knob("MVAE_PERSIST_SAFE");
   a.safe = (sf && atoi(sf) != 0) ? 1 : 0;
   static std::atomic<bool> attr[MVAE_MAX_DEVICES];       // per-device function attribute

@@ -868,7 +868,7 @@ int rnn_rowres_fwd(const mvae_rnn_fwd_desc* d, hipStream_t st) {
       uint32_t* flags = status + 16;
       MVAE_CHECK_HIP(hipMemsetAsync(status, 0, ((size_t)NL * nblk + 16) * sizeof(uint32_t), st));
       const char* sp = mvae_knob("MVAE_ROWRES_SPIN");          // tests: 1 = give up at the first hand-off that is not there yet
-      const uint32_t spin = sp ? (uint32_t)atoi(sp) : (1u << 20);
+      const uint32_t spin = sp ? (uint32_t)atoi(sp) : (1u << 17);
       if (tbl) hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, true>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, spin, d->poison);
       else hipLaunchKernelGGL((lstm_rowres_fwd_pipe_kernel<H, false>), dim3(NL * nblk), dim3(320), 0, st, all, flags, status, spin, d->poison);
       mvae_tls_status = status;
@@ -948,7 +948,7 @@ int rnn_rowres_bwd(const mvae_rnn_bwd_desc* d, hipStream_t st) {
   if (pipe && flags) {
     MVAE_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)NL * nblk + 16) * sizeof(uint32_t), st));     // progress words + status
     const char* sp = mvae_knob("MVAE_ROWRES_SPIN");
-    hipLaunchKernelGGL((lstm_rowres_bwd_pipe_kernel<H>), dim3(NL * nblk), dim3(256), 0, st, all, flags, status, sp ? (uint32_t)atoi(sp) : (1u << 20), d->poison);
+    hipLaunchKernelGGL((lstm_rowres_bwd_pipe_kernel<H>), dim3(NL * nblk), dim3(256), 0, st, all, flags, status, sp ? (uint32_t)atoi(sp) : (1u << 17), d->poison);
     mvae_tls_status = status;              // (the layer-by-layer form has no spins: no status to report, no memset)
   } else {
     hipLaunchKernelGGL((lstm_rowres_bwd_all_kernel<H>), dim3(nblk), dim3(256), 0, st, all);

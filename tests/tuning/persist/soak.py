@@ -15,7 +15,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 dev = torch.device("cuda", 0)
 torch.manual_seed(1)
-model = mv.MolecularVAE(i=120, o=292, c=35, dtype=torch.bfloat16).to(dev)
+NOISE = sys.argv[3] if len(sys.argv) > 3 else "device"
+model = mv.MolecularVAE(i=120, o=292, c=35, dtype=torch.bfloat16, noise=NOISE).to(dev)
+if len(sys.argv) > 4:
+    model.encoder.lmbd.seed_noise(int(sys.argv[4]))
 opt = mv.FusedAdam(model.parameters(), lr=8e-4, max_grad_norm=3.0)
 loss_fn = mv.make_loss_function(120)
 g = torch.Generator().manual_seed(5)
@@ -25,19 +28,16 @@ t0 = time.perf_counter()
 for i in range(N):
     idx = corpus[torch.randint(0, 64, (B,), generator=g)].to(dev)
     ohe = torch.nn.functional.one_hot(idx, 35).float()
-    try:
-        loss = mv.train_step(model, opt, loss_fn, idx, ohe)
-        if i % 50 == 0:
-            ops.persist_check(sync=True)
-            losses.append(float(loss))
-    except mv._lib.MvaeError as e:
-        fails += 1
-        print("step", i, "FAILED:", str(e)[:200])
+    loss = mv.train_step(model, opt, loss_fn, idx, ohe)
+    if i % 50 == 0:
+        fails += ops.persist_check(sync=True)            # (round 5: a launch that gives up is counted and survived, not raised)
+        losses.append(float(loss))
 torch.cuda.synchronize()
-ops.persist_check(sync=True)
+fails += ops.persist_check(sync=True)
 dt = time.perf_counter() - t0
 print(f"B={B}: {N} steps in {dt:.1f} s ({1e3 * dt / N:.2f} ms/step incl. host batch assembly); persistent launches fwd {ops.PERSIST_STATS['launches']} "
-      f"bwd {ops.PERSIST_STATS['bwd_launches']}; failures {fails}")
+      f"bwd {ops.PERSIST_STATS['bwd_launches']}, layer-concurrent encoder passes {ops.PERSIST_STATS['rowres_pipe']}; failures {ops.PERSIST_STATS['failures']}, "
+      f"steps skipped by the optimiser {int(float(opt.skipped_steps))}, schedules disabled: {ops.PERSIST_STATS['disabled']}")
 print("loss every 50 steps:", " ".join(f"{x:.3f}" for x in losses[:6]), "...", " ".join(f"{x:.3f}" for x in losses[-4:]))
 ok = fails == 0 and all(x == x and abs(x) < 1e6 for x in losses) and losses[-1] < 0.7 * losses[0]
 print("RESULT", "OK" if ok else "BAD")
