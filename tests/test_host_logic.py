@@ -69,6 +69,14 @@ def test_counter_normal_host_restatement_and_distribution():
     y, _, _ = ops.normal_draw(1235, 0, n)               # neighbouring seed
     z_, _, _ = ops.normal_draw(1234, n, n)              # the next block of the same stream
     assert abs(np.corrcoef(x, y)[0, 1]) < 5 / np.sqrt(n) and abs(np.corrcoef(x, z_)[0, 1]) < 5 / np.sqrt(n)
+    # the Box-Muller pair (u1, u2) fills the unit square evenly, squares are uncorrelated at the lags that matter (volatility clustering would
+    # not show in the plain correlations above)
+    _, w1, w2 = ops.normal_draw(1234, 0, n)
+    Hh, _, _ = np.histogram2d((w1 >> 8) / 2.0 ** 24, (w2 >> 8) / 2.0 ** 24, bins=32)
+    chi = ((Hh - n / 1024) ** 2 / (n / 1024)).sum()
+    assert 1e-4 < 1 - stats.chi2.cdf(chi, 1023) < 1 - 1e-4, chi
+    for lag in (1, 292, 128 * 292):
+        assert abs(np.corrcoef(x[:-lag] ** 2, x[lag:] ** 2)[0, 1]) < 5 / np.sqrt(n)
     a, _, _ = ops.normal_draw(1234, 100, 50, scale=1e-2)
     assert np.allclose(a, 1e-2 * x[100:150], rtol=1e-14, atol=0)     # a draw depends on (seed, counter) only
 
