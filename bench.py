@@ -13,9 +13,11 @@ init under manual_seed(42), bf16 decoder-LSTM storage / fp32 accumulate + fp32 m
 Inputs are resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline     -- the decoder LSTM wavefront step kernel with the larger share of the step (MFMA bound; at B = 1024 the fused backward step):
-                  algorithmic FLOPs per launch / average launch duration measured live with HIP events on the launching stream; the other
-                  direction's kernel under `other`.
+  roofline     -- the decoder LSTM wavefront step kernel with the larger share of the step (at B = 1024 the fused backward step), priced against
+                  the BINDING roof of that launch: `bound` = "hbm" when its algorithmic bytes / 8 TB/s exceed its algorithmic FLOPs / 2.5 PF/s
+                  (B = 1024: 250 FLOP/B, below the ridge), else "mfma"; algorithmic bytes (or FLOPs) per launch / average launch duration
+                  measured live with HIP events on the launching stream.  Both roofs' figures under `mfma` / `hbm`, the other direction's
+                  kernel under `other`.
   cpu_baseline -- oracle/torch_ref.py (the reference architecture on stock torch.nn, CPU) timed on this host's cores on a bounded
                   sample (rank 0, N = 1 only).
   secondary    -- N = 1 only: the same step at configs[1] (B=512 bf16), at the per-rank shape of configs[2] (b=128 bf16, with its own
@@ -248,13 +250,18 @@ class MolVaeWorkload:
         d, o = leg[dom], leg[oth]
         traffic, src = pmc_traffic(d["pmc_key"], self.B, dtype)
         hbm_bound = dtype == "bf16" and d["floor_us"]["hbm"] > d["floor_us"]["mfma"]
-        # `bound` names the roof the headline fraction is taken against (MFMA: the unit BASELINE's north star asks for); `higher_floor` says which of
-        # the two floors of this launch is the binding one -- at B = 1024 the algorithmic bytes / 8 TB/s exceed the FLOPs / 2.5 PF/s, and
-        # frac_of_higher_floor is the fraction against THAT floor
-        return dict(bound="mfma", kernel=d["kernel"], achieved=round(d["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(d["tflops"] / peak, 4),
+        # `bound` names the BINDING roof of the dominant launch -- the higher of its two floors: at B = 1024 the algorithmic bytes / 8 TB/s exceed
+        # the algorithmic FLOPs / 2.5 PF/s (intensity 250 FLOP/B, below the 312 FLOP/B ridge), so the launch is priced against HBM there and
+        # `achieved` / `peak` / `unit` / `frac` are GB/s; where the MFMA floor is the higher one (persistent passes, small batches) they are
+        # TFLOP/s.  The other roof's figures stand beside it under `mfma` / `hbm` on every line.
+        gbps = d["bytes"] / (d["us"] * 1e-6) / 1e9
+        mfma_obj = dict(achieved=round(d["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(d["tflops"] / peak, 4))
+        hbm_obj = dict(achieved=round(gbps, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBS, 4))
+        head = dict(bound="hbm", **hbm_obj) if hbm_bound else dict(bound="mfma", **mfma_obj)
+        return dict(**head, kernel=d["kernel"], mfma=mfma_obj, hbm=hbm_obj,
                     floors_us=d["floor_us"], higher_floor=("hbm" if hbm_bound else "mfma"),
                     frac_of_higher_floor=round(max(d["floor_us"].values()) / d["us"], 4), algorithmic_bytes_per_launch=int(d["bytes"]),
-                    achieved_GBps_algorithmic=round(d["bytes"] / (d["us"] * 1e-6) / 1e9, 1),
+                    achieved_GBps_algorithmic=round(gbps, 1),
                     traffic=traffic, traffic_source=src, launches_per_pass=n_launch,
                     share_of_step_ms=round(d["us"] * n_launch * 1e-3, 3),
                     avg_launch_us=dict(lstm_step_fwd=round(fwd_us, 2), lstm_step_bwd=round(bwd_us, 2)),
