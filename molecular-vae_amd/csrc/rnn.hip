@@ -1444,10 +1444,13 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     // fills the chip by itself (B = 1024: 31.7 vs 32.4 ms / step in situ against (256 x 128, 2); at B = 512 it has 128 workgroups: 70 vs 49 us)
     // (128 x 64, 1) = the same fused kernel on half-width tiles: B = 512 at 4 x 1024 is 256 of them -- one launch of 3 MB per CU instead of the
     // (128 x 128, 2) GEMM + element-wise pair (MVAE_BWD_SPLIT=641 forces it)
-    static const Cand cand[6] = {{128, 128, 1, 1281}, {128, 64, 1, 641}, {256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
-    for (int c = 0; c < 6 && !nsplit; ++c) {
+    // (256 x 128, 1) = the fused kernel on 256-row tiles (a quarter fewer operand bytes and LDS reads per FLOP than 128 x 128): only where it
+    // still gives a workgroup per CU -- B >= 2048 at 4 x 1024 (BASELINE configs[4]); MVAE_BWD_SPLIT=2561 forces it (tests), MVAE_BWD_256=0 keeps it out
+    static const Cand cand[7] = {{256, 128, 1, 2561}, {128, 128, 1, 1281}, {128, 64, 1, 641}, {256, 128, 2, 2562}, {128, 128, 2, 2}, {128, 128, 4, 1284}, {128, 64, 4, 644}};
+    for (int c = 0; c < 7 && !nsplit; ++c) {
       if (B % cand[c].bm || (cand[c].ns == 4 && (4 * H) % (2 * ke))) continue;
       if (drop && cand[c].ns == 1) continue;      // the unsplit wave-specialised instantiation carries no dropout factor (DROP = false): never with a mask
+      if (cand[c].key == 2561 && split_knob != 2561 && !tune_int("MVAE_BWD_256", 1)) continue;
       const long wgs = (long)(B / cand[c].bm) * (H / cand[c].bn) * cand[c].ns * NL;
       if (split_knob == cand[c].key || (split_knob == 1 && wgs >= (cand[c].ns == 1 ? 256 : 192))) { BM = cand[c].bm; BN = cand[c].bn; nsplit = cand[c].ns; }
     }
@@ -1487,7 +1490,7 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
 #endif
   const int nbuf = pipe ? (drop ? 4 : tune_int("MVAE_NBUF_BWD", 4)) : 0;
   const bool ws = tune_int("MVAE_WS_BWD", 1) != 0;      // loader / consumer wave specialisation of the split-mode GEMM kernel
-  size_t lds = (size_t)(split ? (BM == 256 ? 3 : 4) : big_fused ? 4 : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
+  size_t lds = (size_t)(split ? (BM == 256 ? 3 : 4) : big_fused ? (BM == 256 ? 3 : 4) : (nbuf > 0 ? nbuf : 2)) * (BM + BN) * KB;
   const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   bool want_dh0 = false;
@@ -1540,6 +1543,10 @@ int rnn_bwd_impl(const mvae_rnn_bwd_desc* d, hipStream_t st) {
     if (big_fused) {
       block = dim3(512);
       const int pref = tune_int("MVAE_BWD_PREF", 1);           // 0: the round-2 form (operands requested inside the epilogue), A/B knob
+      if (BM == 256) {              // (the round-2 form of the fused epilogue: the prefetching forms are written out for a ring of four)
+        MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 256, 128, 3, true, false, 0>));
+        continue;
+      }
       if (BN == 64) {
         if (d->dy) MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true, false, 0, 1>));
         else MVAE_STEP_LAUNCH((lstm_step_bwd_kernel<bf16_t, 128, 64, 4, true, false, 0, 2>));

@@ -133,7 +133,7 @@ def _lstm_case(dt, T, B, H, NL, In, seed=2, persist=None):
     return errs
 
 
-@pytest.mark.parametrize("split", ["1", "0", "2", "1284", "644", "1281", "641", "2562"])
+@pytest.mark.parametrize("split", ["1", "0", "2", "1284", "644", "1281", "641", "2562", "2561"])
 def test_lstm_bwd_output_gradient_as_a_product(split, monkeypatch):
     """mvae_rnn_bwd with dy given as dy_a . dy_w^T (contracted by the top layer's cell as its second K-segment) against the same call with the
     materialised fp32 dy = dy_a . dy_w^T, in every backward schedule (fused, 2- and 4-way split, unsplit 128 x 128, 256 x 128)."""
@@ -300,7 +300,7 @@ def test_lstm_tile_variants_vs_oracle(env, monkeypatch):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("split", ["0", "2", "2562", "1284", "644", "1281", "641"])
+@pytest.mark.parametrize("split", ["0", "2", "2562", "1284", "644", "1281", "641", "2561"])
 def test_lstm_bwd_split_segment_schedule(split, monkeypatch):
     """Backward with the contraction split across workgroups -- by K-segment (128x128 or 256x128 partial tiles) or by half segment
     (4 partial tiles per output: the small-batch schedules) + element-wise second launch -- vs the fused single-launch form."""
