@@ -250,12 +250,16 @@ def _lstm_weight_grads(ws, grads, prefix, dt, dev, NL, Lq, B, H, dG, ldg, hs, ld
     G4, TB = 4 * H, Lq * B
     f32 = torch.float32
     layers = range(NL) if layers is None else layers
-    if dt == torch.bfloat16 and Lq > 1 and ops.gemm_tn_grouped_supported(dG[0], G4, H, TB - B, ldg, ldh) and H == 1024 and L.knob("MVAE_DW_GROUPED", "1") != "0":
+    # operands beyond one 2 GiB buffer descriptor (configs[4]: T * B = 524288 rows of 8320 bytes) are cut into K-chunks of whole time steps that
+    # accumulate -- the grouped full-K kernel then serves them too (round 5; before, that size fell back to one split-K GEMM per matrix: 0.81 PFLOP/s)
+    ks_auto = max(1, -(-(TB * max(ldg, ldh) * 2) // ((1 << 31) - (1 << 24))))
+    k_chunk = TB - B if ks_auto == 1 else ((TB // ks_auto + B - 1) // B) * B
+    if dt == torch.bfloat16 and Lq > 1 and ops.gemm_tn_grouped_supported(dG[0], G4, H, k_chunk, ldg, ldh) and H == 1024 and L.knob("MVAE_DW_GROUPED", "1") != "0":
         # ONE grouped launch for every dW_ih / dW_hh of the requested layers (64 tiles of 256 x 256 each, accumulated over the full K = T*B in
         # registers: no split-K slabs, no reduction launch); the bias gradient (column sums of dG) rides along one GEMM per layer.
         # K-chunks (MVAE_DW_KSPLIT, default 1): the same tiles as `ks` shorter launches that accumulate -- a 256 x 256 tile owns its CU for
         # its whole K (3.1 ms at B = 1024), so shorter launches give the dispatcher points at which the other stream's kernels get CUs
-        ks = max(1, int(L.knob("MVAE_DW_KSPLIT", DW_KSPLIT)))
+        ks = max(ks_auto, int(L.knob("MVAE_DW_KSPLIT", DW_KSPLIT)))
         step = ((TB // ks + B - 1) // B) * B if ks > 1 else TB            # whole time steps per chunk
         for k0 in range(0, TB, step):
             k1 = min(TB, k0 + step)
