@@ -32,6 +32,8 @@ for i in range(N):
     if i % 50 == 0:
         fails += ops.persist_check(sync=True)            # (round 5: a launch that gives up is counted and survived, not raised)
         losses.append(float(loss))
+    if i % 1000 == 999:
+        print(f"step {i + 1}: loss {float(loss):.3f}, failures so far {ops.PERSIST_STATS['failures']}", flush=True)
 torch.cuda.synchronize()
 fails += ops.persist_check(sync=True)
 dt = time.perf_counter() - t0
